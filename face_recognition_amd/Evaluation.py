@@ -1,0 +1,113 @@
+"""Drop-in for the reference's ``Evaluation.py`` (LFW / CFP-FP / AgeDB-30 style verification).
+
+Same function names, argument order and return types as ``Mobilefacenet/Evaluation.py:18-99``.
+``getFeature`` runs the embeddings and the flip-TTA combine on the HIP device and returns CPU
+tensors like the reference.  The 10-fold protocol itself is host-side numpy in the reference and
+stays host-side numpy here, with the same array expressions for centring and scoring; only the
+20,001-step threshold sweep is replaced by an exact sorted-count formulation that yields the
+same accuracies, hence bit-identical thresholds, about 1000x faster.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .face_model import MobileFaceNet, l2_norm, tta_combine  # noqa: F401
+
+
+def getAccuracy(scores, flags, threshold, method):
+    """Evaluation.py:18-25 -- strict inequalities on both sides."""
+    if method == "l2_distance":
+        p = np.sum(scores[flags == 1] < threshold)
+        n = np.sum(scores[flags == -1] > threshold)
+    elif method == "cos_distance":
+        p = np.sum(scores[flags == 1] > threshold)
+        n = np.sum(scores[flags == -1] < threshold)
+    else:
+        raise ValueError(f"unknown method {method!r}")
+    return 1.0 * (p + n) / len(scores)
+
+
+def getThreshold(scores, flags, thrNum, method):
+    """Evaluation.py:27-34 -- mean of every threshold on the grid k*3/thrNum (|k| <= thrNum) that
+    attains the maximum accuracy.
+
+    The reference evaluates getAccuracy at each of the 2*thrNum+1 thresholds.  #(s < t) and #(s > t)
+    over a sorted array are two binary searches, so all accuracies come from four searchsorted
+    calls; the comparisons are made in float64 against the float64 grid, as numpy does for a
+    float32 array compared with a float64 scalar, so every count -- and the result -- is identical.
+    """
+    if method not in ("l2_distance", "cos_distance"):
+        raise ValueError(f"unknown method {method!r}")
+    scores = np.asarray(scores)
+    flags = np.asarray(flags)
+    thresholds = np.arange(-thrNum, thrNum + 1) * 3.0 / thrNum
+    pos = np.sort(scores[flags == 1].astype(np.float64))
+    neg = np.sort(scores[flags == -1].astype(np.float64))
+    pos_lt = np.searchsorted(pos, thresholds, side="left")
+    pos_gt = len(pos) - np.searchsorted(pos, thresholds, side="right")
+    neg_lt = np.searchsorted(neg, thresholds, side="left")
+    neg_gt = len(neg) - np.searchsorted(neg, thresholds, side="right")
+    if np.isnan(pos).any() or np.isnan(neg).any():
+        # NaN compares false both ways; searchsorted would put it last and count it as "greater"
+        pos_gt = pos_gt - int(np.isnan(pos).sum())
+        neg_gt = neg_gt - int(np.isnan(neg).sum())
+    correct = (pos_lt + neg_gt) if method == "l2_distance" else (pos_gt + neg_lt)
+    accuracys = 1.0 * correct / len(scores)
+    max_index = accuracys == np.max(accuracys)
+    return np.mean(thresholds[max_index])
+
+
+def getFeature(net, dataloader, device, flip=True):
+    """Evaluation.py:36-66.  ``dataloader`` yields lists ``[L, flip(L), R, flip(R)]`` of f32
+    [b,3,112,112]; returns CPU f32 tensors (featureLs, featureRs) in loader order."""
+    featureLs, featureRs = [], []
+    for det in dataloader:
+        det = [d.to(device, non_blocking=True) for d in det]
+        sizes = [d.size(0) for d in det]
+        with torch.no_grad():
+            res = torch.split(net(torch.cat(det, 0)), sizes, 0)   # one launch sequence for all four
+            if flip:
+                featureL = tta_combine(res[0], res[1])
+                featureR = tta_combine(res[2], res[3])
+            else:
+                featureL, featureR = res[0], res[2]
+        featureLs.append(featureL.cpu())
+        featureRs.append(featureR.cpu())
+    if not featureLs:
+        return None, None
+    return torch.cat(featureLs, 0), torch.cat(featureRs, 0)
+
+
+def evaluation_10_fold(featureL, featureR, dataset, method="l2_distance"):
+    """Evaluation.py:68-99.  ``dataset`` needs ``.folds`` (0..9) and ``.flags`` (+-1).
+
+    Keeps the reference's arithmetic line for line where it decides results: the validation-fold
+    mean is subtracted from the arrays carried into the next fold (:86-89), so the centring
+    accumulates across folds exactly as it does there.
+    """
+    ACCs = np.zeros(10)
+    threshold = np.zeros(10)
+    fold = np.array(dataset.folds).reshape(1, -1)
+    flags = np.array(dataset.flags).reshape(1, -1)
+    featureLs = featureL.numpy() if isinstance(featureL, torch.Tensor) else np.asarray(featureL)
+    featureRs = featureR.numpy() if isinstance(featureR, torch.Tensor) else np.asarray(featureR)
+    for i in range(10):
+        valFold = fold != i
+        testFold = fold == i
+        flags = np.squeeze(flags)
+        mu = np.mean(np.concatenate((featureLs[valFold[0], :], featureRs[valFold[0], :]), 0), 0)
+        mu = np.expand_dims(mu, 0)
+        featureLs = featureLs - mu
+        featureRs = featureRs - mu
+        featureLs = featureLs / np.expand_dims(np.sqrt(np.sum(np.power(featureLs, 2), 1)), 1)
+        featureRs = featureRs / np.expand_dims(np.sqrt(np.sum(np.power(featureRs, 2), 1)), 1)
+        if method == "l2_distance":
+            scores = np.sum(np.power((featureLs - featureRs), 2), 1)
+        elif method == "cos_distance":
+            scores = np.sum(np.multiply(featureLs, featureRs), 1)
+        else:
+            raise ValueError(f"unknown method {method!r}")
+        threshold[i] = getThreshold(scores[valFold[0]], flags[valFold[0]], 10000, method)
+        ACCs[i] = getAccuracy(scores[testFold[0]], flags[testFold[0]], threshold[i], method)
+    return ACCs, threshold

@@ -1,0 +1,83 @@
+"""ctypes binding of libface_recognition_amd.so (the C ABI declared in include/face_recognition_amd.h).
+
+There is no fallback: if the shared object is missing or a call fails, a
+``RuntimeError`` carrying the library's own message is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libface_recognition_amd.so")
+
+FRA_F32, FRA_BF16, FRA_F16 = 0, 1, 2
+DTYPE_BY_NAME = {"f32": FRA_F32, "float32": FRA_F32, "bf16": FRA_BF16, "bfloat16": FRA_BF16,
+                 "f16": FRA_F16, "float16": FRA_F16, "fp16": FRA_F16}
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+# name -> (restype, argtypes); every symbol include/face_recognition_amd.h declares
+_P, _I, _L, _D = C.c_void_p, C.c_int, C.c_int64, C.c_double
+SIGNATURES = {
+    "fra_last_error": (C.c_char_p, []),
+    "fra_version": (_I, []),
+    "mfn_create": (_I, [C.POINTER(_P), _I, _I, _I]),
+    "mfn_load_weights": (_I, [_P, C.POINTER(TensorDesc), _I]),
+    "mfn_workspace_bytes": (_I, [_P, _I, C.POINTER(C.c_size_t)]),
+    "mfn_set_batch_chunk": (_I, [_P, _I]),
+    "mfn_forward": (_I, [_P, _P, _I, _P, _P, C.c_size_t, _P]),
+    "mfn_forward_timed": (_I, [_P, _P, _I, _P, _P, C.c_size_t, _P, C.POINTER(C.c_float), _I]),
+    "mfn_op_count": (_I, [_P]),
+    "mfn_op_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_I), C.POINTER(_D), C.POINTER(_D)]),
+    "mfn_debug_prefix": (_I, [_P, _P, _I, _I, _P, C.POINTER(_L), _P, C.c_size_t, _P]),
+    "mfn_destroy": (_I, [_P]),
+    "mfn_tta_combine": (_I, [_P, _P, _I, _I, _P, _P]),
+    "mfn_op_stem": (_I, [_I, _P, _P, _P, _P, _P, _I, _P]),
+    "mfn_op_dw3x3": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mfn_op_pw": (_I, [_I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "mfn_op_gdconv7": (_I, [_I, _P, _P, _P, _P, _I, _I, _P]),
+    "mfn_op_linear_l2norm": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "fb_create": (_I, [C.POINTER(_P), _I, _P, _I, _L, _I, _I, _L]),
+    "fb_fill": (_I, [_P, _L, _P, _I, _L]),
+    "fb_rows": (_L, [_P]),
+    "fb_search_l2_topk": (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    "fb_merge_topk": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "fb_threshold_score": (_I, [_P, _P, _P, _I, _D, _P]),
+    "fb_destroy": (_I, [_P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared object once and attach signatures.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m face_recognition_amd.build` "
+            "(hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().fra_last_error()
+        raise RuntimeError(f"{what} failed (status {rc}): {msg.decode() if msg else 'no message'}")
+
+
+def current_stream_ptr(device) -> int:
+    import torch
+    return int(torch.cuda.current_stream(device).cuda_stream)

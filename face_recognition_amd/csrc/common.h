@@ -1,0 +1,84 @@
+// Shared declarations for the gfx950 kernels and the C-ABI layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/face_recognition_amd.h"  // status codes and dtype tags (global namespace)
+
+namespace fra {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+
+template <typename T> struct vec8 { typedef T type __attribute__((ext_vector_type(8))); };
+template <typename T> struct vec4 { typedef T type __attribute__((ext_vector_type(4))); };
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// activation / weight element types selectable at handle creation
+enum ActDtype { ACT_F32 = 0, ACT_BF16 = 1, ACT_F16 = 2 };
+
+// one 32x32x16 MFMA step, fp32 accumulate.  Operand maps (lane l, r = l & 31, h = l >> 5):
+//   a[j] = A[row r][k = 8h + j],  b[j] = B[k = 8h + j][col r],
+//   acc[g] = D[row (g & 3) + 8 (g >> 2) + 4 h][col r]
+__device__ __forceinline__ f32x16 mfma32(vec8<f16>::type a, vec8<f16>::type b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(vec8<bf16>::type a, vec8<bf16>::type b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// row of the 32x32 accumulator tile held in register g by a lane of half h
+__device__ __forceinline__ int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+// Status codes come from the public header: FRA_ERR_ARG (bad argument), FRA_ERR_STATE (call
+// order), FRA_ERR_HIP (a HIP runtime call failed), FRA_ERR_WEIGHTS (missing / mis-shaped tensor),
+// FRA_ERR_WORKSPACE (workspace too small).
+
+#define FRA_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            fra::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__,   \
+                           __LINE__);                                                          \
+            return FRA_ERR_HIP;                                                           \
+        }                                                                                      \
+    } while (0)
+
+#define FRA_REQUIRE(cond, code, ...)                                                           \
+    do {                                                                                       \
+        if (!(cond)) {                                                                         \
+            fra::set_error(__VA_ARGS__);                                                       \
+            return code;                                                                       \
+        }                                                                                      \
+    } while (0)
+
+// ---- kernel launchers (device pointers, parameters already in kernel layout) ------------------
+// All return a Status; all launch on `s` and never synchronise.
+
+// stem: x f32 NCHW [B,3,112,112] -> out T NHWC [B,56,56,64]; w f32 [27][64] (tap-major), bias/slope f32 [64]
+int launch_stem(int dt, const float* x, const float* w, const float* bias, const float* slope, void* out, int B,
+                hipStream_t s);
+// depthwise 3x3, pad 1: in T [B,H,W,C] -> out T [B,Ho,Wo,C]; w T [9][C]; slope == nullptr -> linear
+int launch_dw3x3(int dt, const void* in, const void* w, const float* bias, const float* slope, void* out, int B,
+                 int H, int W, int C, int stride, hipStream_t s);
+// pointwise conv as GEMM: out[M,N] = act(in[M,K] . w[N,K]^T + bias) (+ resid[M,N])
+int launch_pw(int dt, const void* in, const void* w, const float* bias, const float* slope, const void* resid,
+              void* out, int64_t M, int K, int N, hipStream_t s);
+// 7x7 global depthwise conv: in T [B,49,C] -> out T [B,C]; w T [49][C]
+int launch_gdconv7(int dt, const void* in, const void* w, const float* bias, void* out, int B, int C, hipStream_t s);
+// embedding head: out f32 [B,E] = l2norm(in[B,K] . w[E,K]^T + bias)
+int launch_linear_l2norm(int dt, const void* in, const void* w, const float* bias, float* out, int B, int K, int E,
+                         hipStream_t s);
+// out = l2norm(a + b) row-wise (b may be nullptr: plain l2norm), f32 [B,E]
+int launch_add_l2norm(const float* a, const float* b, float* out, int B, int E, hipStream_t s);
+// T NHWC [n] -> f32 (debug taps)
+int launch_to_f32(int dt, const void* in, float* out, int64_t n, hipStream_t s);
+
+}  // namespace fra

@@ -1,0 +1,466 @@
+// MobileFaceNet context: state_dict ingestion (BatchNorm folding + repacking), the op schedule,
+// workspace planning and the forward pass.  C-ABI entry points are at the bottom of the file.
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace fra {
+
+static const double kBnEps = 1e-5;  // torch BatchNorm default, face_model.py:30,42,92
+
+enum OpKind { OP_STEM = 0, OP_DW = 1, OP_PW = 2, OP_GDCONV = 3, OP_LINEAR = 4 };
+// per-image activation buffers inside the workspace
+enum Buf { BUF_X = -1, BUF_P0 = 0, BUF_P1 = 1, BUF_E = 2, BUF_D = 3, BUF_V = 4, BUF_OUT = 5, NBUF = 5 };
+static const int64_t kBufElems[NBUF] = {56 * 56 * 64, 56 * 56 * 64, 56 * 56 * 128, 28 * 28 * 128, 512};
+
+struct Op {
+    OpKind kind;
+    std::string name;  // state_dict prefix
+    int in, out, resid;  // Buf ids (resid < -1: none)
+    int cin, cout, hin, hout, stride;
+    bool prelu;
+    // device parameter pointers (into the arena)
+    const void* w = nullptr;
+    const float* bias = nullptr;
+    const float* slope = nullptr;
+    size_t w_off = 0, bias_off = 0, slope_off = 0;  // arena offsets
+    double flops = 0, bytes = 0;                    // per image
+};
+
+static const int NO_RESID = -100;
+
+}  // namespace fra
+
+struct mfn_handle {
+    int device = 0;
+    int E = 512;
+    int dt = fra::ACT_F16;
+    int chunk = 0;
+    bool loaded = false;
+    std::vector<fra::Op> ops;
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+};
+
+namespace fra {
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static void build_ops(mfn_handle* h) {
+    std::vector<Op>& ops = h->ops;
+    const int es = 2;  // bytes per activation / weight element
+    auto add = [&](OpKind k, const std::string& name, int in, int out, int resid, int cin, int cout, int hin,
+                   int hout, int stride, bool prelu) {
+        Op o;
+        o.kind = k; o.name = name; o.in = in; o.out = out; o.resid = resid;
+        o.cin = cin; o.cout = cout; o.hin = hin; o.hout = hout; o.stride = stride; o.prelu = prelu;
+        const double px_in = (double)hin * hin, px_out = (double)hout * hout;
+        switch (k) {
+            case OP_STEM:
+                o.flops = 2.0 * px_out * cout * 27;
+                o.bytes = px_in * 3 * 4 + px_out * cout * es + 27 * 64 * 4;
+                break;
+            case OP_DW:
+                o.flops = 2.0 * px_out * cout * 9;
+                o.bytes = (px_in * cin + px_out * cout) * es + 9.0 * cout * es;
+                break;
+            case OP_PW:
+                o.flops = 2.0 * px_out * cin * cout;
+                o.bytes = (px_in * cin + px_out * cout + (resid != NO_RESID ? px_out * cout : 0)) * es +
+                          (double)cin * cout * es;
+                break;
+            case OP_GDCONV:
+                o.flops = 2.0 * 49 * cout;
+                o.bytes = (49.0 * cin + cout) * es + 49.0 * cout * es;
+                break;
+            case OP_LINEAR:
+                o.flops = 2.0 * cin * cout;
+                o.bytes = cin * es + cout * 4.0 + (double)cin * cout * es;
+                break;
+        }
+        ops.push_back(o);
+    };
+    // face_model.py:80-81
+    add(OP_STEM, "conv1", BUF_X, BUF_P0, NO_RESID, 3, 64, 112, 56, 2, true);
+    add(OP_DW, "conv2_dw", BUF_P0, BUF_P1, NO_RESID, 64, 64, 56, 56, 1, true);
+    int cur = BUF_P1;
+    auto block = [&](const std::string& p, int cin, int cexp, int cout, int stride, bool res, int hin) {
+        const int hout = (hin + 2 - 3) / stride + 1;
+        const int other = cur == BUF_P0 ? BUF_P1 : BUF_P0;
+        add(OP_PW, p + ".conv", cur, BUF_E, NO_RESID, cin, cexp, hin, hin, 1, true);        // face_model.py:51
+        add(OP_DW, p + ".conv_dw", BUF_E, BUF_D, NO_RESID, cexp, cexp, hin, hout, stride, true);  // :52
+        add(OP_PW, p + ".project", BUF_D, other, res ? cur : NO_RESID, cexp, cout, hout, hout, 1, false);  // :53,62
+        cur = other;
+    };
+    // face_model.py:82-87
+    block("conv_23", 64, 128, 64, 2, false, 56);
+    for (int i = 0; i < 4; ++i) block("conv_3.model." + std::to_string(i), 64, 128, 64, 1, true, 28);
+    block("conv_34", 64, 256, 128, 2, false, 28);
+    for (int i = 0; i < 6; ++i) block("conv_4.model." + std::to_string(i), 128, 256, 128, 1, true, 14);
+    block("conv_45", 128, 512, 128, 2, false, 14);
+    for (int i = 0; i < 2; ++i) block("conv_5.model." + std::to_string(i), 128, 256, 128, 1, true, 7);
+    // face_model.py:88-92
+    add(OP_PW, "conv_6_sep", cur, BUF_E, NO_RESID, 128, 512, 7, 7, 1, true);
+    add(OP_GDCONV, "conv_6_dw", BUF_E, BUF_V, NO_RESID, 512, 512, 7, 1, 1, false);
+    add(OP_LINEAR, "linear", BUF_V, BUF_OUT, NO_RESID, 512, h->E, 1, 1, 1, false);
+}
+
+// ---- 16-bit conversions on the host (round to nearest even) ------------------------------------
+static uint16_t f32_to_bf16_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static uint16_t f32_to_f16_bits(float f) {
+    _Float16 hv = (_Float16)f;  // host compiler converts with round-to-nearest-even
+    uint16_t b;
+    memcpy(&b, &hv, 2);
+    return b;
+}
+static uint16_t to16(int dt, float f) { return dt == ACT_BF16 ? f32_to_bf16_bits(f) : f32_to_f16_bits(f); }
+
+struct TensorView {
+    const float* data;
+    int ndim;
+    int64_t shape[4];
+    int64_t numel() const {
+        int64_t n = 1;
+        for (int i = 0; i < ndim; ++i) n *= shape[i];
+        return n;
+    }
+};
+
+static int fetch(const std::map<std::string, TensorView>& m, const std::string& key, int64_t numel,
+                 const float** out) {
+    auto it = m.find(key);
+    FRA_REQUIRE(it != m.end(), FRA_ERR_WEIGHTS, "state_dict is missing key '%s'", key.c_str());
+    FRA_REQUIRE(it->second.data != nullptr, FRA_ERR_WEIGHTS, "state_dict key '%s' has a null data pointer",
+                key.c_str());
+    FRA_REQUIRE(it->second.numel() == numel, FRA_ERR_WEIGHTS, "state_dict key '%s' has %lld elements, expected %lld",
+                key.c_str(), (long long)it->second.numel(), (long long)numel);
+    *out = it->second.data;
+    return FRA_OK;
+}
+
+// scale[c] = gamma / sqrt(var + eps), shift[c] = beta - mean * scale     (eval-mode BatchNorm)
+static int bn_fold(const std::map<std::string, TensorView>& m, const std::string& prefix, int C,
+                   std::vector<double>& scale, std::vector<double>& shift) {
+    const float *g, *b, *mu, *var;
+    int rc;
+    if ((rc = fetch(m, prefix + ".weight", C, &g))) return rc;
+    if ((rc = fetch(m, prefix + ".bias", C, &b))) return rc;
+    if ((rc = fetch(m, prefix + ".running_mean", C, &mu))) return rc;
+    if ((rc = fetch(m, prefix + ".running_var", C, &var))) return rc;
+    scale.resize(C);
+    shift.resize(C);
+    for (int c = 0; c < C; ++c) {
+        scale[c] = (double)g[c] / sqrt((double)var[c] + kBnEps);
+        shift[c] = (double)b[c] - (double)mu[c] * scale[c];
+    }
+    return FRA_OK;
+}
+
+static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
+    std::map<std::string, TensorView> m;
+    for (int i = 0; i < n; ++i) {
+        FRA_REQUIRE(tensors[i].name != nullptr, FRA_ERR_WEIGHTS, "tensor %d has no name", i);
+        FRA_REQUIRE(tensors[i].ndim >= 0 && tensors[i].ndim <= 4, FRA_ERR_WEIGHTS, "tensor '%s': ndim %d",
+                    tensors[i].name, tensors[i].ndim);
+        std::string key = tensors[i].name;
+        if (key.compare(0, 7, "module.") == 0) key = key.substr(7);  // nn.DataParallel checkpoints
+        TensorView v;
+        v.data = tensors[i].data;
+        v.ndim = tensors[i].ndim;
+        for (int d = 0; d < 4; ++d) v.shape[d] = d < tensors[i].ndim ? tensors[i].shape[d] : 1;
+        m[key] = v;
+    }
+    const int dt = h->dt;
+    // plan the arena
+    size_t off = 0;
+    for (Op& o : h->ops) {
+        size_t wbytes = 0;
+        switch (o.kind) {
+            case OP_STEM: wbytes = 27 * 64 * 4; break;
+            case OP_DW: wbytes = 9 * (size_t)o.cout * 2; break;
+            case OP_PW: wbytes = (size_t)o.cin * o.cout * 2; break;
+            case OP_GDCONV: wbytes = 49 * (size_t)o.cout * 2; break;
+            case OP_LINEAR: wbytes = (size_t)o.cin * o.cout * 2; break;
+        }
+        o.w_off = off; off = align_up(off + wbytes, 256);
+        o.bias_off = off; off = align_up(off + (size_t)o.cout * 4, 256);
+        o.slope_off = off; off = align_up(off + (size_t)o.cout * 4, 256);
+    }
+    std::vector<unsigned char> host(off, 0);
+    for (Op& o : h->ops) {
+        std::vector<double> scale, shift;
+        const float* w = nullptr;
+        int rc;
+        const int C = o.cout;
+        float* bias = reinterpret_cast<float*>(host.data() + o.bias_off);
+        float* slope = reinterpret_cast<float*>(host.data() + o.slope_off);
+        if (o.kind == OP_LINEAR) {
+            if ((rc = fetch(m, "linear.weight", (int64_t)o.cin * C, &w))) return rc;
+            if ((rc = bn_fold(m, "bn", C, scale, shift))) return rc;
+            uint16_t* dst = reinterpret_cast<uint16_t*>(host.data() + o.w_off);
+            for (int e = 0; e < C; ++e)
+                for (int k = 0; k < o.cin; ++k) dst[(size_t)e * o.cin + k] = to16(dt, (float)(w[(size_t)e * o.cin + k] * scale[e]));
+            for (int e = 0; e < C; ++e) bias[e] = (float)shift[e];
+            continue;
+        }
+        const int kk = o.kind == OP_STEM ? 27 : o.kind == OP_DW ? 9 : o.kind == OP_GDCONV ? 49 : o.cin;
+        if ((rc = fetch(m, o.name + ".conv.weight", (int64_t)C * kk, &w))) return rc;
+        if ((rc = bn_fold(m, o.name + ".bn", C, scale, shift))) return rc;
+        for (int c = 0; c < C; ++c) bias[c] = (float)shift[c];
+        if (o.prelu) {
+            const float* a;
+            if ((rc = fetch(m, o.name + ".prelu.weight", C, &a))) return rc;
+            for (int c = 0; c < C; ++c) slope[c] = a[c];
+        }
+        if (o.kind == OP_STEM) {
+            // torch [oc][c][ky][kx] -> [tap = (c*3+ky)*3+kx][oc], fp32
+            float* dst = reinterpret_cast<float*>(host.data() + o.w_off);
+            for (int oc = 0; oc < 64; ++oc)
+                for (int t = 0; t < 27; ++t) dst[t * 64 + oc] = (float)(w[oc * 27 + t] * scale[oc]);
+        } else if (o.kind == OP_DW || o.kind == OP_GDCONV) {
+            // torch [c][1][ky][kx] -> [tap][c]
+            uint16_t* dst = reinterpret_cast<uint16_t*>(host.data() + o.w_off);
+            for (int c = 0; c < C; ++c)
+                for (int t = 0; t < kk; ++t) dst[(size_t)t * C + c] = to16(dt, (float)(w[(size_t)c * kk + t] * scale[c]));
+        } else {  // OP_PW: torch [oc][ic][1][1] keeps its layout, rows scaled
+            uint16_t* dst = reinterpret_cast<uint16_t*>(host.data() + o.w_off);
+            for (int oc = 0; oc < C; ++oc)
+                for (int k = 0; k < o.cin; ++k) dst[(size_t)oc * o.cin + k] = to16(dt, (float)(w[(size_t)oc * o.cin + k] * scale[oc]));
+        }
+    }
+    FRA_HIP(hipSetDevice(h->device));
+    if (h->arena_bytes < off) {
+        if (h->arena) FRA_HIP(hipFree(h->arena));
+        h->arena = nullptr;
+        FRA_HIP(hipMalloc(&h->arena, off));
+        h->arena_bytes = off;
+    }
+    FRA_HIP(hipMemcpy(h->arena, host.data(), off, hipMemcpyHostToDevice));
+    for (Op& o : h->ops) {
+        o.w = static_cast<char*>(h->arena) + o.w_off;
+        o.bias = reinterpret_cast<const float*>(static_cast<char*>(h->arena) + o.bias_off);
+        o.slope = o.prelu ? reinterpret_cast<const float*>(static_cast<char*>(h->arena) + o.slope_off) : nullptr;
+    }
+    h->loaded = true;
+    return FRA_OK;
+}
+
+// workspace layout for a slice of `b` images: the five buffers back to back, 256-byte aligned
+struct WsPlan {
+    size_t off[NBUF];
+    size_t total;
+};
+static WsPlan plan_ws(int b) {
+    WsPlan p;
+    size_t off = 0;
+    for (int i = 0; i < NBUF; ++i) {
+        p.off[i] = off;
+        off = align_up(off + (size_t)kBufElems[i] * 2 * (size_t)b, 256);
+    }
+    p.total = off;
+    return p;
+}
+
+static int slice_size(const mfn_handle* h, int B) { return (h->chunk > 0 && h->chunk < B) ? h->chunk : B; }
+
+static int run_op(const mfn_handle* h, const Op& o, const float* x, float* out, char* ws, const WsPlan& p, int b,
+                  hipStream_t s) {
+    auto buf = [&](int id) -> void* { return ws + p.off[id]; };
+    switch (o.kind) {
+        case OP_STEM:
+            return launch_stem(h->dt, x, (const float*)o.w, o.bias, o.slope, buf(o.out), b, s);
+        case OP_DW:
+            return launch_dw3x3(h->dt, buf(o.in), o.w, o.bias, o.slope, buf(o.out), b, o.hin, o.hin, o.cin, o.stride, s);
+        case OP_PW:
+            return launch_pw(h->dt, buf(o.in), o.w, o.bias, o.slope, o.resid != NO_RESID ? buf(o.resid) : nullptr,
+                             buf(o.out), (int64_t)b * o.hout * o.hout, o.cin, o.cout, s);
+        case OP_GDCONV:
+            return launch_gdconv7(h->dt, buf(o.in), o.w, o.bias, buf(o.out), b, o.cout, s);
+        case OP_LINEAR:
+            return launch_linear_l2norm(h->dt, buf(o.in), o.w, o.bias, out, b, o.cin, o.cout, s);
+    }
+    return FRA_ERR_ARG;
+}
+
+static int check_forward_args(const mfn_handle* h, const float* x, int B, const void* out, const void* ws,
+                              size_t ws_bytes) {
+    FRA_REQUIRE(h != nullptr, FRA_ERR_ARG, "null handle");
+    FRA_REQUIRE(h->loaded, FRA_ERR_STATE, "mfn_forward called before mfn_load_weights");
+    FRA_REQUIRE(x && out && ws, FRA_ERR_ARG, "mfn_forward: null pointer");
+    FRA_REQUIRE(B > 0, FRA_ERR_ARG, "mfn_forward: batch %d", B);
+    const size_t need = plan_ws(slice_size(h, B)).total;
+    FRA_REQUIRE(ws_bytes >= need, FRA_ERR_WORKSPACE, "workspace has %zu bytes, batch %d needs %zu", ws_bytes, B, need);
+    FRA_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0, FRA_ERR_ARG,
+                "mfn_forward: workspace must be 256-byte aligned, input/output 16-byte aligned");
+    return FRA_OK;
+}
+
+static int forward(mfn_handle* h, const float* x, int B, float* out, void* ws, size_t ws_bytes, hipStream_t s,
+                   float* op_ms, int n_ops_timed) {
+    int rc = check_forward_args(h, x, B, out, ws, ws_bytes);
+    if (rc) return rc;
+    const int nops = (int)h->ops.size();
+    const int sl = slice_size(h, B);
+    std::vector<hipEvent_t> ev;
+    if (op_ms) {
+        FRA_REQUIRE(n_ops_timed >= nops, FRA_ERR_ARG, "op_ms has room for %d ops, model has %d", n_ops_timed, nops);
+        for (int i = 0; i < nops; ++i) op_ms[i] = 0.0f;
+        ev.resize(nops + 1);
+        for (auto& e : ev) FRA_HIP(hipEventCreate(&e));
+    }
+    for (int b0 = 0; b0 < B; b0 += sl) {
+        const int b = (B - b0) < sl ? (B - b0) : sl;
+        const WsPlan p = plan_ws(b);
+        const float* xs = x + (size_t)b0 * 3 * 112 * 112;
+        float* os = out + (size_t)b0 * h->E;
+        if (op_ms) FRA_HIP(hipEventRecord(ev[0], s));
+        for (int i = 0; i < nops; ++i) {
+            rc = run_op(h, h->ops[i], xs, os, static_cast<char*>(ws), p, b, s);
+            if (rc) return rc;
+            if (op_ms) FRA_HIP(hipEventRecord(ev[i + 1], s));
+        }
+        if (op_ms) {
+            FRA_HIP(hipEventSynchronize(ev[nops]));
+            for (int i = 0; i < nops; ++i) {
+                float ms = 0;
+                FRA_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+                op_ms[i] += ms;
+            }
+        }
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return FRA_OK;
+}
+
+}  // namespace fra
+
+using namespace fra;
+
+extern "C" {
+
+int mfn_create(mfn_handle** out, int device, int embedding_size, int act_dtype) {
+    FRA_REQUIRE(out != nullptr, FRA_ERR_ARG, "mfn_create: null output pointer");
+    *out = nullptr;
+    FRA_REQUIRE(act_dtype == ACT_F16 || act_dtype == ACT_BF16, FRA_ERR_ARG,
+                "mfn_create: act_dtype %d unsupported (1 = bf16, 2 = f16)", act_dtype);
+    FRA_REQUIRE(embedding_size == 128 || embedding_size == 256 || embedding_size == 512 || embedding_size == 1024,
+                FRA_ERR_ARG, "mfn_create: embedding_size %d unsupported (128, 256, 512, 1024)", embedding_size);
+    int count = 0;
+    FRA_HIP(hipGetDeviceCount(&count));
+    FRA_REQUIRE(device >= 0 && device < count, FRA_ERR_ARG, "mfn_create: device %d not in [0,%d)", device, count);
+    mfn_handle* h = new mfn_handle();
+    h->device = device;
+    h->E = embedding_size;
+    h->dt = act_dtype;
+    build_ops(h);
+    *out = h;
+    return FRA_OK;
+}
+
+int mfn_load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
+    FRA_REQUIRE(h && tensors && n > 0, FRA_ERR_ARG, "mfn_load_weights: bad argument");
+    return load_weights(h, tensors, n);
+}
+
+int mfn_workspace_bytes(const mfn_handle* h, int max_batch, size_t* bytes) {
+    FRA_REQUIRE(h && bytes && max_batch > 0, FRA_ERR_ARG, "mfn_workspace_bytes: bad argument");
+    *bytes = plan_ws(slice_size(h, max_batch)).total;
+    return FRA_OK;
+}
+
+int mfn_set_batch_chunk(mfn_handle* h, int images) {
+    FRA_REQUIRE(h && images >= 0, FRA_ERR_ARG, "mfn_set_batch_chunk: bad argument");
+    h->chunk = images;
+    return FRA_OK;
+}
+
+int mfn_forward(mfn_handle* h, const float* x, int B, float* out, void* ws, size_t ws_bytes, fra_stream stream) {
+    return forward(h, x, B, out, ws, ws_bytes, (hipStream_t)stream, nullptr, 0);
+}
+
+int mfn_forward_timed(mfn_handle* h, const float* x, int B, float* out, void* ws, size_t ws_bytes, fra_stream stream,
+                      float* op_ms, int n_ops) {
+    FRA_REQUIRE(op_ms != nullptr, FRA_ERR_ARG, "mfn_forward_timed: null op_ms");
+    return forward(h, x, B, out, ws, ws_bytes, (hipStream_t)stream, op_ms, n_ops);
+}
+
+int mfn_op_count(const mfn_handle* h) { return h ? (int)h->ops.size() : -1; }
+
+int mfn_op_info(const mfn_handle* h, int op, char* name, int name_cap, int* kind, double* flops, double* bytes) {
+    FRA_REQUIRE(h && op >= 0 && op < (int)h->ops.size(), FRA_ERR_ARG, "mfn_op_info: bad argument");
+    const Op& o = h->ops[op];
+    if (name && name_cap > 0) {
+        strncpy(name, o.name.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (kind) *kind = (int)o.kind;
+    if (flops) *flops = o.flops;
+    if (bytes) *bytes = o.bytes;
+    return FRA_OK;
+}
+
+int mfn_debug_prefix(mfn_handle* h, const float* x, int B, int n_ops, float* out_f32, int64_t* numel_per_image,
+                     void* ws, size_t ws_bytes, fra_stream stream) {
+    int rc = check_forward_args(h, x, B, out_f32, ws, ws_bytes);
+    if (rc) return rc;
+    FRA_REQUIRE(n_ops >= 1 && n_ops < (int)h->ops.size(), FRA_ERR_ARG,
+                "mfn_debug_prefix: n_ops %d not in [1,%d)", n_ops, (int)h->ops.size());
+    FRA_REQUIRE(slice_size(h, B) == B, FRA_ERR_STATE, "mfn_debug_prefix: batch chunking must be off");
+    const WsPlan p = plan_ws(B);
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < n_ops; ++i) {
+        rc = run_op(h, h->ops[i], x, nullptr, static_cast<char*>(ws), p, B, s);
+        if (rc) return rc;
+    }
+    const Op& o = h->ops[n_ops - 1];
+    const int64_t per = (int64_t)o.hout * o.hout * o.cout;
+    if (numel_per_image) *numel_per_image = per;
+    return launch_to_f32(h->dt, static_cast<char*>(ws) + p.off[o.out], out_f32, per * B, s);
+}
+
+int mfn_destroy(mfn_handle* h) {
+    if (!h) return FRA_OK;
+    if (h->arena) {
+        (void)hipSetDevice(h->device);
+        (void)hipFree(h->arena);
+    }
+    delete h;
+    return FRA_OK;
+}
+
+int mfn_tta_combine(const float* a, const float* b, int B, int E, float* out, fra_stream stream) {
+    return launch_add_l2norm(a, b, out, B, E, (hipStream_t)stream);
+}
+
+int mfn_op_stem(int dtype, const float* x, const float* w, const float* bias, const float* slope, void* out, int B,
+                fra_stream stream) {
+    return launch_stem(dtype, x, w, bias, slope, out, B, (hipStream_t)stream);
+}
+int mfn_op_dw3x3(int dtype, const void* in, const void* w, const float* bias, const float* slope, void* out, int B,
+                 int H, int W, int C, int stride, fra_stream stream) {
+    return launch_dw3x3(dtype, in, w, bias, slope, out, B, H, W, C, stride, (hipStream_t)stream);
+}
+int mfn_op_pw(int dtype, const void* in, const void* w, const float* bias, const float* slope, const void* resid,
+              void* out, int64_t M, int K, int N, fra_stream stream) {
+    return launch_pw(dtype, in, w, bias, slope, resid, out, M, K, N, (hipStream_t)stream);
+}
+int mfn_op_gdconv7(int dtype, const void* in, const void* w, const float* bias, void* out, int B, int C,
+                   fra_stream stream) {
+    return launch_gdconv7(dtype, in, w, bias, out, B, C, (hipStream_t)stream);
+}
+int mfn_op_linear_l2norm(int dtype, const void* in, const void* w, const float* bias, float* out, int B, int K, int E,
+                         fra_stream stream) {
+    return launch_linear_l2norm(dtype, in, w, bias, out, B, K, E, (hipStream_t)stream);
+}
+
+}  // extern "C"

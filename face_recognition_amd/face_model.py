@@ -1,0 +1,269 @@
+"""Drop-in for the reference's ``face_model.MobileFaceNet`` / ``l2_norm`` on MI355X.
+
+``MobileFaceNet(embedding_size)`` is a ``torch.nn.Module`` whose parameter tree carries exactly
+the reference's 333 state_dict keys (``Mobilefacenet/face_model.py:77-92``), so checkpoints load
+unchanged; ``forward`` (``face_model.py:103-129``) does not run those modules: it hands the input
+to the HIP library, which runs the whole network with BatchNorm folded and PReLU / residual /
+L2-norm fused into hand-written gfx950 kernels.  Inference (eval-mode) semantics only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from . import layers as L
+
+
+def l2_norm(input: torch.Tensor, axis: int = 1) -> torch.Tensor:
+    """``input / ||input||_2`` along ``axis``, no epsilon (reference: face_model.py:19-22).
+
+    Contiguous f32 [B,E] tensors on the HIP device with ``axis=1`` use the row-normalisation
+    kernel; anything else (CPU tensors, other axes) is computed with the reference's two torch ops.
+    """
+    if input.is_cuda and input.dtype == torch.float32 and input.dim() == 2 and axis in (1, -1) \
+            and input.is_contiguous() and input.numel() > 0:
+        lib = _lib.load()
+        out = torch.empty_like(input)
+        with torch.cuda.device(input.device):
+            _lib.check(lib.mfn_tta_combine(input.data_ptr(), None, input.shape[0], input.shape[1], out.data_ptr(),
+                                           _lib.current_stream_ptr(input.device)), "mfn_tta_combine")
+        return out
+    norm = torch.norm(input, 2, axis, True)
+    return torch.div(input, norm)
+
+
+def tta_combine(emb: torch.Tensor, emb_mirror: torch.Tensor) -> torch.Tensor:
+    """``l2_norm(emb + emb_mirror)`` in one kernel (facebank.py:62, cam_demo.py:92, Evaluation.py:51-52)."""
+    if not (emb.is_cuda and emb_mirror.is_cuda):
+        return l2_norm(emb + emb_mirror)
+    a = emb.contiguous().float()
+    b = emb_mirror.contiguous().float()
+    if a.shape != b.shape or a.dim() != 2:
+        raise RuntimeError(f"tta_combine: shapes {tuple(a.shape)} and {tuple(b.shape)} differ or are not [B,E]")
+    lib = _lib.load()
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.mfn_tta_combine(a.data_ptr(), b.data_ptr(), a.shape[0], a.shape[1], out.data_ptr(),
+                                       _lib.current_stream_ptr(a.device)), "mfn_tta_combine")
+    return out
+
+
+class _ConvUnit(nn.Module):
+    """Parameter holder for conv (+bn, +prelu): keys ``conv.weight``, ``bn.*``, ``prelu.weight``."""
+
+    def __init__(self, spec: L.ConvSpec):
+        super().__init__()
+        self.conv = nn.Conv2d(spec.cin, spec.cout, spec.k, spec.stride, spec.pad, groups=spec.groups, bias=False)
+        self.bn = nn.BatchNorm2d(spec.cout)
+        if spec.prelu:
+            self.prelu = nn.PReLU(spec.cout)
+
+
+class _Block(nn.Module):
+    def __init__(self, spec: L.BlockSpec):
+        super().__init__()
+        e, d, p = spec.convs()
+        self.conv, self.conv_dw, self.project = _ConvUnit(e), _ConvUnit(d), _ConvUnit(p)
+
+
+class _Stage(nn.Module):
+    def __init__(self, blocks):
+        super().__init__()
+        self.model = nn.Sequential(*[_Block(b) for b in blocks])
+
+
+class MobileFaceNet(nn.Module):
+    """MobileFaceNet(embedding_size); ``forward(x)``: f32 [B,3,112,112] (BGR, [-1,1]) on the HIP
+    device -> new f32 [B,embedding_size] tensor with unit-norm rows."""
+
+    def __init__(self, embedding_size: int = 512, act_dtype: str = "f16"):
+        super().__init__()
+        self.embedding_size = int(embedding_size)
+        self._act_dtype = _lib.DTYPE_BY_NAME[act_dtype]
+        blocks: Dict[str, list] = {}
+        for b in L.BLOCKS:
+            blocks.setdefault(b.prefix.split(".")[0], []).append(b)
+        self.conv1 = _ConvUnit(L.STEM)
+        self.conv2_dw = _ConvUnit(L.CONV2_DW)
+        self.conv_23 = _Block(blocks["conv_23"][0])
+        self.conv_3 = _Stage(blocks["conv_3"])
+        self.conv_34 = _Block(blocks["conv_34"][0])
+        self.conv_4 = _Stage(blocks["conv_4"])
+        self.conv_45 = _Block(blocks["conv_45"][0])
+        self.conv_5 = _Stage(blocks["conv_5"])
+        self.conv_6_sep = _ConvUnit(L.CONV6_SEP)
+        self.conv_6_dw = _ConvUnit(L.CONV6_DW)
+        self.linear = nn.Linear(L.FEAT_C, self.embedding_size, bias=False)
+        self.bn = nn.BatchNorm1d(self.embedding_size)
+        # same initial distribution as the reference (face_model.py:95-101)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2.0 / n))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+        # native state (not part of the state_dict)
+        self._handle: Optional[int] = None
+        self._handle_device: Optional[torch.device] = None
+        self._dirty = True
+        self._workspace: Optional[torch.Tensor] = None
+        self._batch_chunk = 0
+
+    # ---- weight life cycle --------------------------------------------------------------------
+    def _apply(self, fn, *args, **kwargs):
+        self._dirty = True
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kwargs):
+        """Accepts the reference's checkpoints as they are written: a plain state_dict, keys with
+        the ``module.`` prefix nn.DataParallel adds (test_lfw_agedb_cfpfp.py:63-67), or the training
+        wrapper ``{'net_state_dict': ...}`` (Train_mobile.py:167-176)."""
+        if "net_state_dict" in state_dict and not any(k.endswith(".weight") for k in state_dict):
+            state_dict = state_dict["net_state_dict"]
+        if any(k.startswith("module.") for k in state_dict):
+            state_dict = {k[7:] if k.startswith("module.") else k: v for k, v in state_dict.items()}
+        self._dirty = True
+        return super().load_state_dict(state_dict, strict=strict, **kwargs)
+
+    def refresh_weights(self) -> None:
+        """Call after modifying parameters in place; load_state_dict / .to() do this themselves."""
+        self._dirty = True
+
+    def set_batch_chunk(self, images: int) -> None:
+        """Process large batches in slices of ``images`` (0 = whole batch)."""
+        self._batch_chunk = int(images)
+        if self._handle is not None:
+            _lib.check(_lib.load().mfn_set_batch_chunk(self._handle, self._batch_chunk), "mfn_set_batch_chunk")
+
+    def _ensure_handle(self, device: torch.device):
+        lib = _lib.load()
+        if self._handle is not None and self._handle_device != device:
+            lib.mfn_destroy(self._handle)
+            self._handle = None
+        if self._handle is None:
+            h = C.c_void_p()
+            _lib.check(lib.mfn_create(C.byref(h), device.index if device.index is not None else
+                                      torch.cuda.current_device(), self.embedding_size, self._act_dtype),
+                       "mfn_create")
+            self._handle, self._handle_device, self._dirty = h.value, device, True
+            _lib.check(lib.mfn_set_batch_chunk(self._handle, self._batch_chunk), "mfn_set_batch_chunk")
+        if self._dirty:
+            sd = self.state_dict()
+            keep, descs = [], (_lib.TensorDesc * len(sd))()
+            n = 0
+            for k, v in sd.items():
+                if k.endswith("num_batches_tracked"):
+                    continue
+                a = v.detach().to("cpu", torch.float32).contiguous()
+                keep.append(a)
+                descs[n].name = k.encode()
+                descs[n].data = a.data_ptr()
+                descs[n].ndim = a.dim()
+                for d in range(a.dim()):
+                    descs[n].shape[d] = a.shape[d]
+                n += 1
+            _lib.check(lib.mfn_load_weights(self._handle, descs, n), "mfn_load_weights")
+            self._dirty = False
+        return lib
+
+    def _ensure_workspace(self, lib, batch: int, device: torch.device) -> torch.Tensor:
+        need = C.c_size_t()
+        _lib.check(lib.mfn_workspace_bytes(self._handle, batch, C.byref(need)), "mfn_workspace_bytes")
+        ws = self._workspace
+        if ws is None or ws.device != device or ws.numel() < need.value:
+            self._workspace = None
+            ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+            self._workspace = ws
+        return ws
+
+    # ---- forward --------------------------------------------------------------------------------
+    def _check_input(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            raise RuntimeError("MobileFaceNet (face_recognition_amd) is inference-only: call .eval() first")
+        if not isinstance(x, torch.Tensor) or x.dim() != 4 or tuple(x.shape[1:]) != (3, L.INPUT_HW, L.INPUT_HW):
+            raise RuntimeError(f"expected input [B,3,112,112], got {tuple(getattr(x, 'shape', ()))}")
+        if not x.is_cuda:
+            raise RuntimeError("MobileFaceNet (face_recognition_amd) runs on the HIP device only; "
+                               "move the model and the input to 'cuda' (there is no CPU path)")
+        if x.shape[0] == 0:
+            raise RuntimeError("empty batch")
+        return x.detach().to(torch.float32).contiguous()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = self._check_input(x)
+        dev = x.device
+        with torch.cuda.device(dev):
+            lib = self._ensure_handle(dev)
+            ws = self._ensure_workspace(lib, x.shape[0], dev)
+            out = torch.empty((x.shape[0], self.embedding_size), dtype=torch.float32, device=dev)
+            _lib.check(lib.mfn_forward(self._handle, x.data_ptr(), x.shape[0], out.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), _lib.current_stream_ptr(dev)), "mfn_forward")
+        return out
+
+    def embed_tta(self, x: torch.Tensor) -> torch.Tensor:
+        """``l2_norm(net(x) + net(hflip(x)))`` -- the flip test-time augmentation of facebank.py:59-62."""
+        return tta_combine(self.forward(x), self.forward(torch.flip(x, dims=[3])))
+
+    def forward_timed(self, x: torch.Tensor):
+        """(embeddings, per-op milliseconds, op table) -- benchmark helper, synchronises."""
+        x = self._check_input(x)
+        dev = x.device
+        with torch.cuda.device(dev):
+            lib = self._ensure_handle(dev)
+            ws = self._ensure_workspace(lib, x.shape[0], dev)
+            out = torch.empty((x.shape[0], self.embedding_size), dtype=torch.float32, device=dev)
+            n = lib.mfn_op_count(self._handle)
+            ms = (C.c_float * n)()
+            _lib.check(lib.mfn_forward_timed(self._handle, x.data_ptr(), x.shape[0], out.data_ptr(), ws.data_ptr(),
+                                             ws.numel(), _lib.current_stream_ptr(dev), ms, n), "mfn_forward_timed")
+        return out, np.array(list(ms), dtype=np.float64), self.op_table()
+
+    def op_table(self):
+        """[(name, kind, flops_per_image, bytes_per_image)] for every kernel of the forward."""
+        lib = _lib.load()
+        if self._handle is None:
+            raise RuntimeError("op_table: run a forward first")
+        kinds = ["stem", "dw3x3", "pw", "gdconv7", "linear"]
+        rows = []
+        for i in range(lib.mfn_op_count(self._handle)):
+            name = C.create_string_buffer(96)
+            kind, fl, by = C.c_int(), C.c_double(), C.c_double()
+            _lib.check(lib.mfn_op_info(self._handle, i, name, 96, C.byref(kind), C.byref(fl), C.byref(by)),
+                       "mfn_op_info")
+            rows.append((name.value.decode(), kinds[kind.value], fl.value, by.value))
+        return rows
+
+    def debug_prefix(self, x: torch.Tensor, n_ops: int) -> torch.Tensor:
+        """Activation after the first ``n_ops`` kernels as f32 NHWC [B,H,W,C] (test helper)."""
+        x = self._check_input(x)
+        dev = x.device
+        with torch.cuda.device(dev):
+            lib = self._ensure_handle(dev)
+            ws = self._ensure_workspace(lib, x.shape[0], dev)
+            out = torch.empty(x.shape[0] * 56 * 56 * 128, dtype=torch.float32, device=dev)
+            per = C.c_int64()
+            _lib.check(lib.mfn_debug_prefix(self._handle, x.data_ptr(), x.shape[0], n_ops, out.data_ptr(),
+                                            C.byref(per), ws.data_ptr(), ws.numel(),
+                                            _lib.current_stream_ptr(dev)), "mfn_debug_prefix")
+        return out[: x.shape[0] * per.value].view(x.shape[0], -1)
+
+    def __getstate__(self):
+        # native handles are per process and per object: copies and pickles rebuild their own
+        d = self.__dict__.copy()
+        d.update(_handle=None, _handle_device=None, _workspace=None, _dirty=True)
+        return d
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None:
+                _lib.load().mfn_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass

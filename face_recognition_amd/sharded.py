@@ -1,0 +1,115 @@
+"""Multi-GPU layout: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI).
+
+Only two things shard, and they shard differently:
+
+* embedding is data parallel -- every rank embeds its own contiguous slice of the crops with a
+  full copy of the (2.4 MB) weights; there is NO collective on that path;
+* 1:N search is gallery-row parallel -- rank r owns rows [r*N/R, (r+1)*N/R) (``index_base`` =
+  first row), the queries are replicated, every rank computes its local top-k with global
+  indices, and ONE all-gather of (distance, index) pairs (Q*k*8 bytes per rank) followed by a
+  local merge gives every rank the global top-k.  Ordering (ascending distance, ties to the
+  lowest index) is the same in the shard search and in the merge, so the result equals the
+  single-GPU search of the whole gallery.
+
+The search and merge steps are injectable so that the partition / gather / merge plumbing can be
+exercised with the gloo backend on hosts without a GPU; by default they are the HIP kernels.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced partition of ``total`` items: first (total % world) ranks get one extra."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} not in [0,{world})")
+    base, extra = divmod(total, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def _hip_merge(dist_parts: torch.Tensor, idx_parts: torch.Tensor, k: int):
+    from .facebank import merge_topk
+    return merge_topk(dist_parts, idx_parts, k)
+
+
+def allgather_topk(local_dist: torch.Tensor, local_idx: torch.Tensor, group=None
+                   ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """All-gather per-shard candidate lists: ([Q,k] f32, [Q,k] i32) -> ([R,Q,k] f32, [R,Q,k] i32).
+
+    Distances and indices travel in one message: the f32 bits are viewed as int32 and packed next
+    to the indices, so each rank contributes a single [Q,2k] int32 buffer."""
+    world = dist.get_world_size(group)
+    q, k = local_dist.shape
+    packed = torch.empty((q, 2 * k), dtype=torch.int32, device=local_dist.device)
+    packed[:, :k] = local_dist.contiguous().view(torch.int32)
+    packed[:, k:] = local_idx.to(torch.int32)
+    gathered = torch.empty((world, q, 2 * k), dtype=torch.int32, device=local_dist.device)
+    dist.all_gather_into_tensor(gathered.view(world * q, 2 * k), packed, group=group)
+    d = gathered[:, :, :k].contiguous().view(torch.float32)
+    i = gathered[:, :, k:].contiguous()
+    return d, i
+
+
+class ShardedGallery:
+    """This rank's shard of a row-sharded gallery plus the gather / merge step.
+
+    ``local_search(queries, k) -> (dist f32 [Q,k], idx int32 [Q,k])`` must report GLOBAL row indices
+    (the HIP ``Gallery`` does when built with ``index_base`` = first row of the shard).
+    """
+
+    def __init__(self, total_rows: int, local_search: Callable, group=None,
+                 merge: Optional[Callable] = None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.total_rows = int(total_rows)
+        self.row_begin, self.row_end = shard_bounds(self.total_rows, self.world, self.rank)
+        self.local_search = local_search
+        self.merge = merge or _hip_merge
+
+    @classmethod
+    def from_rows(cls, local_rows: torch.Tensor, total_rows: int, store: str = "f16", group=None):
+        """Build the HIP shard from this rank's rows (rows [row_begin,row_end) of the whole gallery)."""
+        from .facebank import Gallery
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        b, e = shard_bounds(total_rows, world, rank)
+        if local_rows.shape[0] != e - b:
+            raise RuntimeError(f"rank {rank} owns rows [{b},{e}) but was given {local_rows.shape[0]} rows")
+        g = Gallery(local_rows, store=store, index_base=b)
+        sg = cls(total_rows, g.search, group)
+        sg.gallery = g
+        return sg
+
+    def search(self, queries: torch.Tensor, k: int = 5) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Global top-k for replicated ``queries``: (dist f32 [Q,k], idx int32 [Q,k]); same on every rank."""
+        ld, li = self.local_search(queries, k)
+        if self.world == 1:
+            return ld, li
+        gd, gi = allgather_topk(ld, li, self.group)
+        return self.merge(gd, gi, k)
+
+
+def split_batch(total: int, group=None) -> Tuple[int, int]:
+    """Slice of a batch of ``total`` crops this rank embeds (data parallel, no collective)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    return shard_bounds(total, world, rank)
+
+
+def gather_embeddings(local_emb: torch.Tensor, total: int, group=None) -> torch.Tensor:
+    """Optional: assemble [total,E] embeddings on every rank from the per-rank slices of ``split_batch``."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local_emb
+    sizes = [shard_bounds(total, world, r) for r in range(world)]
+    maxn = max(e - b for b, e in sizes)
+    pad = torch.zeros((maxn, local_emb.shape[1]), dtype=local_emb.dtype, device=local_emb.device)
+    pad[: local_emb.shape[0]] = local_emb
+    out = torch.empty((world * maxn, local_emb.shape[1]), dtype=local_emb.dtype, device=local_emb.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return torch.cat([out[r * maxn: r * maxn + (e - b)] for r, (b, e) in enumerate(sizes)], 0)

@@ -1,0 +1,145 @@
+/*
+ * face_recognition_amd -- C ABI of the MI355X (gfx950) face-embedding and facebank-search library.
+ *
+ * The reference project (liusheng134/Face_Recognition) has no native or FFI layer: its callers
+ * import Python symbols.  Each entry point below therefore cites the Python interface whose work
+ * it performs; the Python package `face_recognition_amd` re-creates those interfaces (same names,
+ * arguments, return types) on top of this ABI through ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a non-zero fra_status otherwise; fra_last_error()
+ *     returns a thread-local, NUL-terminated description of the last failure on this thread;
+ *   - no C++ exceptions cross this boundary, no torch types appear in it;
+ *   - "dev" pointers are device memory owned by the caller and must stay valid until the work
+ *     queued on `stream` has completed; all launches go to the caller's stream and return
+ *     without synchronising unless stated otherwise;
+ *   - a handle may be used from one thread at a time.
+ */
+#ifndef FACE_RECOGNITION_AMD_H
+#define FACE_RECOGNITION_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fra_stream;           /* a hipStream_t (NULL = the default stream) */
+typedef struct mfn_handle mfn_handle;
+typedef struct fb_handle fb_handle;
+
+enum fra_status {
+    FRA_OK = 0, FRA_ERR_ARG = 1, FRA_ERR_STATE = 2, FRA_ERR_HIP = 3, FRA_ERR_WEIGHTS = 4, FRA_ERR_WORKSPACE = 5
+};
+enum fra_dtype { FRA_F32 = 0, FRA_BF16 = 1, FRA_F16 = 2 };
+
+/* One entry of a state_dict: key name as the reference module registers it
+ * (e.g. "conv_3.model.0.conv_dw.bn.running_var"), host pointer to float32 data, shape. */
+typedef struct {
+    const char* name;
+    const float* data;      /* host memory, contiguous, float32 */
+    int32_t ndim;
+    int64_t shape[4];
+} mfn_tensor_desc;
+
+const char* fra_last_error(void);
+int fra_version(void);
+
+/* ---- MobileFaceNet embedding forward ----------------------------------------------------------
+ * Replaces MobileFaceNet.__init__/forward: Mobilefacenet/face_model.py:77-129. */
+
+/* Create a model context on HIP device `device`.  act_dtype: FRA_F16 or FRA_BF16 storage of
+ * activations and weights (arithmetic accumulates in fp32).  face_model.py:78 (embedding_size). */
+int mfn_create(mfn_handle** out, int device, int embedding_size, int act_dtype);
+
+/* Load a state_dict (the 333 keys of face_model.py:80-92; "num_batches_tracked" entries may be
+ * omitted; a leading "module." is ignored).  Folds every BatchNorm into the preceding conv /
+ * linear layer (eps 1e-5), repacks to the kernels' layouts and uploads.  Synchronous.
+ * Replaces Module.load_state_dict as used at cam_demo.py:52, Evaluation.py:110, facebank.py:88. */
+int mfn_load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n);
+
+/* Bytes of device workspace mfn_forward needs for batches up to max_batch. */
+int mfn_workspace_bytes(const mfn_handle* h, int max_batch, size_t* bytes);
+
+/* Process the batch in slices of `images` (0 = whole batch at once).  Smaller slices keep the
+ * layer-to-layer activations inside the 256 MB Infinity Cache. */
+int mfn_set_batch_chunk(mfn_handle* h, int images);
+
+/* x: dev f32 [B,3,112,112] NCHW (BGR, [-1,1]) -> out: dev f32 [B,embedding_size], rows unit L2 norm.
+ * Replaces MobileFaceNet.forward: face_model.py:103-129. */
+int mfn_forward(mfn_handle* h, const float* x_nchw, int B, float* out, void* workspace, size_t workspace_bytes,
+                fra_stream stream);
+
+/* Same forward, bracketing every kernel with events on `stream`; synchronises; op_ms[i] receives
+ * the milliseconds of op i (see mfn_op_count / mfn_op_info).  For benchmarks only. */
+int mfn_forward_timed(mfn_handle* h, const float* x_nchw, int B, float* out, void* workspace,
+                      size_t workspace_bytes, fra_stream stream, float* op_ms, int n_ops);
+int mfn_op_count(const mfn_handle* h);
+/* kind: 0 stem, 1 depthwise 3x3, 2 pointwise, 3 gdconv 7x7, 4 linear+l2norm.  flops / bytes are the
+ * algorithmic work and HBM traffic (inputs + outputs + weights) of the op for ONE image. */
+int mfn_op_info(const mfn_handle* h, int op, char* name, int name_cap, int* kind, double* flops_per_image,
+                double* bytes_per_image);
+
+/* Debug tap: run the first n_ops ops on x and write that op's output activation, converted to
+ * f32, NHWC, to out_nhwc_f32 (dev).  *numel_per_image receives its per-image element count. */
+int mfn_debug_prefix(mfn_handle* h, const float* x_nchw, int B, int n_ops, float* out_nhwc_f32,
+                     int64_t* numel_per_image, void* workspace, size_t workspace_bytes, fra_stream stream);
+
+int mfn_destroy(mfn_handle* h);
+
+/* out = (a + b) / ||a + b||_2 row-wise, dev f32 [B,E]; b == NULL gives l2_norm(a).
+ * Replaces l2_norm (face_model.py:19-22, axis=1) and the flip-TTA combine
+ * l2_norm(emb + emb_mirror): facebank.py:62, cam_demo.py:92, Evaluation.py:51-52. */
+int mfn_tta_combine(const float* a, const float* b, int B, int E, float* out, fra_stream stream);
+
+/* ---- single kernels, exposed for unit tests (parameters already folded / in kernel layout) ---- */
+int mfn_op_stem(int dtype, const float* x, const float* w27x64, const float* bias, const float* slope, void* out,
+                int B, fra_stream stream);
+int mfn_op_dw3x3(int dtype, const void* in, const void* w9xC, const float* bias, const float* slope_or_null,
+                 void* out, int B, int H, int W, int C, int stride, fra_stream stream);
+int mfn_op_pw(int dtype, const void* in, const void* wNxK, const float* bias, const float* slope_or_null,
+              const void* resid_or_null, void* out, int64_t M, int K, int N, fra_stream stream);
+int mfn_op_gdconv7(int dtype, const void* in, const void* w49xC, const float* bias, void* out, int B, int C,
+                   fra_stream stream);
+int mfn_op_linear_l2norm(int dtype, const void* in, const void* wExK, const float* bias, float* out, int B, int K,
+                         int E, fra_stream stream);
+
+/* ---- facebank: 1:N matching and top-k search -----------------------------------------------------
+ * Replaces the inline match of the demos (cam_demo.py:96-105, Video_demo.py:99-108,
+ * MTCNN_MobileFaceNet.py:76-85) on the tensor load_facebank returns (facebank.py:79-83). */
+
+/* Build a gallery on `device` from N rows of D floats (host or device memory; `gallery_is_device`
+ * says which).  store_dtype FRA_F32 keeps rows in fp32 for the exact small-facebank match;
+ * FRA_F16 / FRA_BF16 pack them for the MFMA search and precompute ||g||^2 from the packed values.
+ * index_base is added to every index reported (row offset of this shard in the whole gallery). */
+int fb_create(fb_handle** out, int device, const float* gallery, int gallery_is_device, int64_t N, int D,
+              int store_dtype, int64_t index_base);
+/* Write rows [row0, row0+n) of a gallery created with gallery == NULL (or overwrite rows); lets a
+ * large shard be produced piecewise on the device.  Synchronous. */
+int fb_fill(fb_handle* h, int64_t row0, const float* rows, int rows_is_device, int64_t n);
+int64_t fb_rows(const fb_handle* h);
+
+/* dist_out[q,j], idx_out[q,j] (dev, [Q,k]) = the k smallest squared L2 distances
+ * sum_d (q[d]-g[n,d])^2 and their (global) indices, ascending; equal distances -> lowest index.
+ * Slots beyond the gallery size hold distance +inf and index -1.  1 <= k <= 8.
+ * Generalises  minimum, min_idx = torch.min(dist, dim=1)  of cam_demo.py:97-99. */
+int fb_search_l2_topk(fb_handle* h, const float* queries, int Q, int k, float* dist_out, int32_t* idx_out,
+                      fra_stream stream);
+
+/* Merge R lists of k candidates per query (dist_in / idx_in dev [R,Q,k], e.g. the result of an
+ * all-gather of per-shard fb_search_l2_topk outputs) into the k best, same ordering rules. */
+int fb_merge_topk(const float* dist_in, const int32_t* idx_in, int R, int Q, int k, float* dist_out,
+                  int32_t* idx_out, fra_stream stream);
+
+/* Demo post-processing on top-1 results (cam_demo.py:100,105): idx_io[q] = -1 where
+ * minimum[q] > (threshold-156)/(-80); score_100[q] = clamp(-80*minimum[q]+156, 0, 100). */
+int fb_threshold_score(const float* minimum, int64_t* idx_io, float* score_100, int Q, double threshold,
+                       fra_stream stream);
+
+int fb_destroy(fb_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FACE_RECOGNITION_AMD_H */

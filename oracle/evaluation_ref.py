@@ -1,0 +1,93 @@
+"""CPU oracle for the 10-fold verification protocol.  TEST INFRASTRUCTURE ONLY.
+
+Restates ``Mobilefacenet/Evaluation.py:18-99`` of the reference in numpy with
+the same arithmetic, loop order and dtypes, including the two behaviours that
+are easy to lose in a rewrite: the fold-wise mean-centring re-assigns the
+loop-carried arrays, so it accumulates from fold to fold (``:86-89``), and the
+best threshold is the mean of every threshold that reaches the best accuracy
+(``:32-33``).  Nothing under ``face_recognition_amd/`` may import this file.
+
+Pinning: ``tests/golden/make_golden.py`` imported the reference's own
+``Evaluation.py`` (with empty stand-in modules for the ``cv2`` and
+``torchvision`` imports it never uses on this path) and recorded its results
+on seeded features in ``tests/golden/eval10fold_*.npz``; this file reproduces
+them exactly.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+import torch
+
+from .mobilefacenet_ref import l2_norm
+
+
+def get_accuracy(scores, flags, threshold, method) -> float:
+    """Evaluation.py:18-25 -- strict inequalities; a score equal to the threshold counts for neither side."""
+    if method == "l2_distance":
+        p = np.sum(scores[flags == 1] < threshold)
+        n = np.sum(scores[flags == -1] > threshold)
+    elif method == "cos_distance":
+        p = np.sum(scores[flags == 1] > threshold)
+        n = np.sum(scores[flags == -1] < threshold)
+    else:
+        raise ValueError(method)
+    return 1.0 * (p + n) / len(scores)
+
+
+def get_threshold(scores, flags, thr_num, method) -> float:
+    """Evaluation.py:27-34 -- sweep 2*thr_num+1 thresholds in [-3,3]; mean of all arg-max thresholds."""
+    accuracys = np.zeros((2 * thr_num + 1, 1))
+    thresholds = np.arange(-thr_num, thr_num + 1) * 3.0 / thr_num
+    for i in range(2 * thr_num + 1):
+        accuracys[i] = get_accuracy(scores, flags, thresholds[i], method)
+    max_index = np.squeeze(accuracys == np.max(accuracys))
+    return float(np.mean(thresholds[max_index]))
+
+
+def evaluation_10_fold(feature_l: np.ndarray, feature_r: np.ndarray, folds, flags,
+                       method: str = "l2_distance", thr_num: int = 10000
+                       ) -> Tuple[np.ndarray, np.ndarray]:
+    """Evaluation.py:68-99.  feature_*: f32 [P,D]; folds ints 0..9; flags +-1."""
+    accs = np.zeros(10)
+    threshold = np.zeros(10)
+    fold = np.array(folds).reshape(1, -1)
+    flags = np.array(flags).reshape(1, -1)
+    fl = np.asarray(feature_l)
+    fr = np.asarray(feature_r)
+    for i in range(10):
+        val = fold != i
+        test = fold == i
+        flags = np.squeeze(flags)
+        mu = np.mean(np.concatenate((fl[val[0], :], fr[val[0], :]), 0), 0)     # :84
+        mu = np.expand_dims(mu, 0)
+        fl = fl - mu                                                           # :86 (carried to next fold)
+        fr = fr - mu
+        fl = fl / np.expand_dims(np.sqrt(np.sum(np.power(fl, 2), 1)), 1)       # :88
+        fr = fr / np.expand_dims(np.sqrt(np.sum(np.power(fr, 2), 1)), 1)
+        if method == "l2_distance":
+            scores = np.sum(np.power((fl - fr), 2), 1)                         # :92
+        elif method == "cos_distance":
+            scores = np.sum(np.multiply(fl, fr), 1)                            # :94
+        else:
+            raise ValueError(method)
+        threshold[i] = get_threshold(scores[val[0]], flags[val[0]], thr_num, method)
+        accs[i] = get_accuracy(scores[test[0]], flags[test[0]], threshold[i], method)
+    return accs, threshold
+
+
+def get_feature(embed_fn, batches, flip: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Evaluation.py:36-66.  ``batches`` yields lists [L, flip(L), R, flip(R)]; ``embed_fn`` maps
+    f32 [b,3,112,112] -> f32 [b,E] (CPU).  Returns CPU tensors in loader order."""
+    ls, rs = [], []
+    for det in batches:
+        res = [embed_fn(d) for d in det]
+        if flip:
+            fl = l2_norm(res[0] + res[1])
+            fr = l2_norm(res[2] + res[3])
+        else:
+            fl, fr = res[0], res[2]
+        ls.append(fl)
+        rs.append(fr)
+    return torch.cat(ls, 0), torch.cat(rs, 0)

@@ -1,0 +1,147 @@
+"""Facebank matching on the GPU against the oracle (the demos' own expressions / fp64 brute force)
+and the golden results recorded on the facebank the reference ships."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from face_recognition_amd import synthetic
+from face_recognition_amd.facebank import Gallery, match_facebank, merge_topk, topk_search
+from oracle import matching_ref as mref
+
+pytestmark = pytest.mark.gpu
+
+
+def test_shipped_facebank_golden(device, golden_dir):
+    z = np.load(os.path.join(golden_dir, "facebank_match.npz"))
+    fb = torch.from_numpy(z["facebank"]).to(device)
+    q = torch.from_numpy(z["queries"]).to(device)
+    for th in (60, 50):
+        mn, idx, sc = match_facebank(q, fb, threshold=th)
+        assert idx.dtype == torch.int64 and mn.dtype == torch.float32
+        assert np.array_equal(idx.cpu().numpy(), z[f"idx_th{th}"])
+        assert np.allclose(mn.cpu().numpy(), z[f"min_th{th}"], rtol=1e-5, atol=2e-6)
+        assert np.allclose(sc.cpu().numpy(), z[f"score_th{th}"], rtol=1e-5, atol=2e-4)
+    names = z["names"]
+    mn, idx, _ = match_facebank(fb, fb)
+    assert [names[i + 1] for i in idx.cpu().tolist()] == list(names[1:])
+    assert float(mn.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("Q,N", [(32, 1000), (1, 5), (8, 77), (3, 1)])
+def test_match_vs_reference_expression(device, Q, N):
+    t = torch.from_numpy(synthetic.unit_rows(N, 512, seed=2))
+    t[N // 2] *= 0.8                        # non-unit row: mean of several embeddings (facebank.py:68)
+    q, truth = synthetic.planted_queries(t.numpy(), Q, seed=4, target_cos=0.75)
+    q = torch.from_numpy(q)
+    want_min, want_idx, want_score = mref.match_broadcast(q, t, 60.0)
+    mn, idx, sc = match_facebank(q.to(device), t.to(device), 60)
+    assert np.array_equal(idx.cpu().numpy(), want_idx.numpy())
+    assert np.allclose(mn.cpu().numpy(), want_min.numpy(), rtol=1e-5, atol=2e-6)
+    assert np.allclose(sc.cpu().numpy(), want_score.numpy(), rtol=1e-5, atol=3e-4)
+
+
+def test_exact_ties_pick_lowest_index(device):
+    g = synthetic.unit_rows(20, 512, seed=12)
+    g[13] = g[4]
+    g[17] = g[4]
+    q = g[[4, 13]] + 0.0
+    for store in ("f32", "f16"):
+        gal = Gallery(torch.from_numpy(g), store=store, device=device)
+        d, i = gal.search(torch.from_numpy(q).to(device), 3)
+        assert i.cpu().tolist() == [[4, 13, 17], [4, 13, 17]], store
+
+
+def _check_topk(dist, idx, queries, gallery, k, tie_tol):
+    """Top-1 identical to fp64 brute force except near-ties (|delta d2| < tie_tol); every returned
+    distance is the true distance of the returned row within tolerance; lists ascending."""
+    bd, bi = mref.l2_topk_bruteforce(queries, gallery, k)
+    dist = dist.cpu().numpy().astype(np.float64)
+    idx = idx.cpu().numpy().astype(np.int64)
+    assert (np.diff(dist, axis=1) >= -1e-6).all()
+    mism = idx[:, 0] != bi[:, 0]
+    if mism.any():
+        g64 = gallery.astype(np.float64)
+        q64 = queries.astype(np.float64)
+        d_mine = ((q64[mism] - g64[idx[mism, 0]]) ** 2).sum(1)
+        assert (np.abs(d_mine - bd[mism, 0]) < tie_tol).all(), "top-1 differs beyond the near-tie tolerance"
+    true_d = ((queries.astype(np.float64)[:, None, :] - gallery.astype(np.float64)[idx]) ** 2).sum(-1)
+    assert np.abs(true_d - dist).max() < tie_tol
+    # every returned row is at least as close as the true k-th neighbour, up to the near-tie tolerance
+    assert (true_d <= bd[:, k - 1:k] + tie_tol).all()
+    assert all(len(set(row)) == k for row in idx.tolist()), "duplicate rows in a top-k list"
+    recall = np.mean([len(set(idx[i]) & set(bi[i])) / k for i in range(len(idx))])
+    return float(mism.mean()), recall
+
+
+@pytest.mark.parametrize("Q,N,k", [(300, 20000, 5), (1, 4097, 5), (17, 64, 8), (40, 130, 1), (5, 3, 5), (257, 70000, 5)])
+def test_topk_f16_vs_bruteforce(device, Q, N, k):
+    g = synthetic.unit_rows(N, 512, seed=3)
+    q, truth = synthetic.planted_queries(g, Q, seed=4, target_cos=0.7)
+    gal = Gallery(torch.from_numpy(g), store="f16", device=device)
+    dist, idx = gal.search(torch.from_numpy(q).to(device), k)
+    kk = min(k, N)
+    if N < k:
+        assert (idx[:, N:] == -1).all() and torch.isinf(dist[:, N:]).all()
+    mism, recall = _check_topk(dist[:, :kk], idx[:, :kk], q, g, kk, 1e-3)
+    planted = truth >= 0
+    assert (idx.cpu().numpy()[planted, 0] == truth[planted]).all()
+    print(f"Q={Q} N={N} k={k}: top-1 mismatch {mism:.4f}, top-{kk} recall {recall:.4f}")
+    assert recall > 0.99   # fp16 rounding may swap the 5th and 6th neighbour when they are near-tied
+
+
+def test_topk_f32_exact(device):
+    g = synthetic.unit_rows(500, 512, seed=3) * np.linspace(0.7, 1.0, 500, dtype=np.float32)[:, None]
+    q, _ = synthetic.planted_queries(g, 20, seed=4)
+    d, i = topk_search(torch.from_numpy(q).to(device), torch.from_numpy(g).to(device), k=5, store="f32")
+    bd, bi = mref.l2_topk_bruteforce(q, g, 5)
+    assert i.dtype == torch.int64 and np.array_equal(i.cpu().numpy(), bi)
+    assert np.allclose(d.cpu().numpy(), bd, rtol=1e-5, atol=2e-6)
+
+
+def test_f32_gallery_other_width(device):
+    g = synthetic.unit_rows(50, 128, seed=3)
+    q = synthetic.unit_rows(4, 128, seed=5)
+    d, i = topk_search(torch.from_numpy(q).to(device), torch.from_numpy(g).to(device), k=2)
+    bd, bi = mref.l2_topk_bruteforce(q, g, 2)
+    assert np.array_equal(i.cpu().numpy(), bi)
+
+
+def test_sharded_search_equals_whole(device):
+    """Row shards with index_base + merge == search of the whole gallery (what 8 GPUs do with an
+    all-gather in between)."""
+    N, Q, k, R = 30000, 64, 5, 4
+    g = synthetic.unit_rows(N, 512, seed=3)
+    q, _ = synthetic.planted_queries(g, Q, seed=4)
+    qd = torch.from_numpy(q).to(device)
+    whole = Gallery(torch.from_numpy(g), store="f16", device=device)
+    wd, wi = whole.search(qd, k)
+    bounds = [(r * N // R, (r + 1) * N // R) for r in range(R)]
+    parts = [Gallery(torch.from_numpy(g[b:e]), store="f16", device=device, index_base=b).search(qd, k) for b, e in bounds]
+    md, mi = merge_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), k)
+    assert torch.equal(mi, wi)
+    assert torch.allclose(md, wd, rtol=0, atol=1e-6)
+    od, oi = mref.merge_topk(np.stack([p[0].cpu().numpy() for p in parts]), np.stack([p[1].cpu().numpy() for p in parts]), k)
+    assert np.array_equal(mi.cpu().numpy(), oi)
+
+
+def test_gallery_fill_piecewise(device):
+    g = synthetic.unit_rows(1000, 512, seed=3)
+    q = torch.from_numpy(synthetic.unit_rows(9, 512, seed=8)).to(device)
+    a = Gallery(torch.from_numpy(g), store="f16", device=device).search(q, 5)
+    gal = Gallery(None, n=1000, d=512, store="f16", device=device)
+    gal.fill(0, torch.from_numpy(g[:300]).to(device))
+    gal.fill(300, torch.from_numpy(g[300:]))           # host rows
+    b = gal.search(q, 5)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
+
+
+def test_facebank_errors(device):
+    with pytest.raises(RuntimeError):
+        Gallery(torch.zeros((4, 100)), store="f16", device=device)      # packed search needs D == 512
+    gal = Gallery(torch.from_numpy(synthetic.unit_rows(8, 512)), store="f32", device=device)
+    with pytest.raises(RuntimeError):
+        gal.search(torch.zeros((2, 512), device=device), 9)
+    with pytest.raises(RuntimeError):
+        gal.search(torch.zeros((2, 100), device=device), 1)

@@ -1,0 +1,197 @@
+"""Each HIP kernel, called through the C ABI, against the same op in plain PyTorch fp32 on the
+same (16-bit rounded) operands.  Tolerances: the kernels accumulate in fp32 and round once to the
+16-bit output, so the error bound is one output rounding (2^-11 relative for f16, 2^-8 for bf16)
+plus fp32 summation-order noise."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from face_recognition_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f16": (torch.float16, _lib.FRA_F16, 2.0 ** -10), "bf16": (torch.bfloat16, _lib.FRA_BF16, 2.0 ** -7)}
+
+
+def stream(dev):
+    return _lib.current_stream_ptr(dev)
+
+
+def close(out, ref, rel, what):
+    out = out.float().cpu()
+    ref = ref.float().cpu()
+    err = (out - ref).abs()
+    tol = rel * ref.abs() + rel * ref.abs().max() * 0.05 + 1e-6
+    bad = (err > tol)
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {err.max():.4g} (ref max {ref.abs().max():.4g})"
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("B", [1, 3])
+def test_stem(device, dt, B):
+    tdt, code, rel = DT[dt]
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand((B, 3, 112, 112), generator=g) * 2 - 1
+    w = torch.randn((64, 3, 3, 3), generator=g) * 0.2
+    bias = torch.randn(64, generator=g) * 0.1
+    slope = torch.rand(64, generator=g) * 0.3 + 0.1
+    ref = F.prelu(F.conv2d(x, w, bias, 2, 1), slope).permute(0, 2, 3, 1).contiguous()
+    wk = w.reshape(64, 27).t().contiguous()       # [tap][oc]
+    xd, wd, bd, sd = (t.to(device) for t in (x, wk, bias, slope))
+    out = torch.empty((B, 56, 56, 64), dtype=tdt, device=device)
+    _lib.check(lib.mfn_op_stem(code, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), sd.data_ptr(), out.data_ptr(), B,
+                               stream(device)), "stem")
+    torch.cuda.synchronize()
+    close(out, ref, rel, "stem")
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("B,H,C,stride,prelu", [(2, 56, 64, 1, True), (1, 56, 128, 2, True), (3, 28, 128, 1, True),
+                                                (2, 28, 256, 2, True), (2, 14, 256, 1, True), (1, 14, 512, 2, True),
+                                                (5, 7, 256, 1, True), (2, 14, 64, 1, False)])
+def test_dw3x3(device, dt, B, H, C, stride, prelu):
+    tdt, code, rel = DT[dt]
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn((B, C, H, H), generator=g)).to(tdt).float()
+    w = (torch.randn((C, 1, 3, 3), generator=g) * 0.3).to(tdt).float()
+    bias = torch.randn(C, generator=g) * 0.1
+    slope = torch.rand(C, generator=g) * 0.3 + 0.1
+    y = F.conv2d(x, w, bias, stride, 1, 1, C)
+    ref = (F.prelu(y, slope) if prelu else y).permute(0, 2, 3, 1).contiguous()
+    Ho = ref.shape[1]
+    xin = x.permute(0, 2, 3, 1).contiguous().to(tdt).to(device)
+    wk = w.reshape(C, 9).t().contiguous().to(tdt).to(device)      # [tap][c]
+    bd, sd = bias.to(device), slope.to(device)
+    out = torch.empty((B, Ho, Ho, C), dtype=tdt, device=device)
+    _lib.check(lib.mfn_op_dw3x3(code, xin.data_ptr(), wk.data_ptr(), bd.data_ptr(), sd.data_ptr() if prelu else None,
+                                out.data_ptr(), B, H, H, C, stride, stream(device)), "dw3x3")
+    torch.cuda.synchronize()
+    close(out, ref, rel, f"dw3x3 H={H} C={C} s={stride}")
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("M,K,N,prelu,resid", [(3136, 64, 128, True, False), (784, 128, 64, False, True),
+                                               (784 * 2 + 5, 64, 256, True, False), (196, 256, 128, False, True),
+                                               (196 * 3, 128, 512, True, False), (49, 512, 128, False, False),
+                                               (49 * 5, 128, 256, True, False), (49, 256, 128, False, True),
+                                               (1, 64, 64, False, False), (130, 128, 192, True, True)])
+def test_pw(device, dt, M, K, N, prelu, resid):
+    tdt, code, rel = DT[dt]
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn((M, K), generator=g).to(tdt)
+    w = (torch.randn((N, K), generator=g) / np.sqrt(K)).to(tdt)
+    bias = torch.randn(N, generator=g) * 0.1
+    slope = torch.rand(N, generator=g) * 0.3 + 0.1
+    r = torch.randn((M, N), generator=g).to(tdt)
+    ref = a.float() @ w.float().t() + bias
+    if prelu:
+        ref = torch.where(ref > 0, ref, ref * slope)
+    if resid:
+        ref = ref + r.float()
+    ad, wd, bd, sd, rd = (t.to(device) for t in (a, w, bias, slope, r))
+    out = torch.full((M, N), float("nan"), dtype=tdt, device=device)
+    _lib.check(lib.mfn_op_pw(code, ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), sd.data_ptr() if prelu else None,
+                             rd.data_ptr() if resid else None, out.data_ptr(), M, K, N, stream(device)), "pw")
+    torch.cuda.synchronize()
+    close(out, ref, rel, f"pw M={M} K={K} N={N}")
+
+
+def test_pw_orientation_asymmetric(device):
+    """A = identity against an asymmetric weight matrix exposes a transposed output or operand map."""
+    lib = _lib.load()
+    K = N = 64
+    a = torch.eye(K, dtype=torch.float16)
+    w = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 61 - 30).to(torch.float16)
+    bias = torch.zeros(N)
+    ad, wd, bd = a.to(device), w.to(device), bias.to(device)
+    out = torch.empty((K, N), dtype=torch.float16, device=device)
+    _lib.check(lib.mfn_op_pw(_lib.FRA_F16, ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, None, out.data_ptr(), K,
+                             K, N, stream(device)), "pw")
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu().float(), w.float().t())
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("B", [1, 70])
+def test_gdconv7(device, dt, B):
+    tdt, code, rel = DT[dt]
+    lib = _lib.load()
+    C_ = 512
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((B, C_, 7, 7), generator=g).to(tdt).float()
+    w = (torch.randn((C_, 1, 7, 7), generator=g) * 0.15).to(tdt).float()
+    bias = torch.randn(C_, generator=g) * 0.1
+    ref = F.conv2d(x, w, bias, 1, 0, 1, C_).reshape(B, C_)
+    xin = x.permute(0, 2, 3, 1).contiguous().to(tdt).to(device)
+    wk = w.reshape(C_, 49).t().contiguous().to(tdt).to(device)
+    out = torch.empty((B, C_), dtype=tdt, device=device)
+    bd = bias.to(device)
+    _lib.check(lib.mfn_op_gdconv7(code, xin.data_ptr(), wk.data_ptr(), bd.data_ptr(), out.data_ptr(), B, C_,
+                                  stream(device)), "gdconv7")
+    torch.cuda.synchronize()
+    close(out, ref, rel, "gdconv7")
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("B,E", [(1, 512), (33, 512), (64, 128), (5, 256), (40, 1024)])
+def test_linear_l2norm(device, dt, B, E):
+    tdt, code, rel = DT[dt]
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn((B, 512), generator=g).to(tdt)
+    w = (torch.randn((E, 512), generator=g) / 22.0).to(tdt)
+    bias = torch.randn(E, generator=g) * 0.1
+    y = a.float() @ w.float().t() + bias
+    ref = y / y.norm(dim=1, keepdim=True)
+    out = torch.full((B, E), float("nan"), dtype=torch.float32, device=device)
+    ad, wd, bd = a.to(device), w.to(device), bias.to(device)   # keep the device copies alive
+    _lib.check(lib.mfn_op_linear_l2norm(code, ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, 512, E,
+                                        stream(device)), "linear")
+    torch.cuda.synchronize()
+    assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=2e-6), (out.cpu() - ref).abs().max()
+    assert torch.allclose(out.cpu().norm(dim=1), torch.ones(B), atol=1e-5)
+
+
+@pytest.mark.parametrize("B,E", [(1, 512), (7, 512), (130, 128), (3, 100)])
+def test_tta_combine_and_l2norm(device, B, E):
+    from face_recognition_amd.face_model import l2_norm, tta_combine
+    g = torch.Generator().manual_seed(6)
+    a, b = torch.randn((B, E), generator=g), torch.randn((B, E), generator=g)
+    ref = (a + b) / (a + b).norm(dim=1, keepdim=True)
+    out = tta_combine(a.to(device), b.to(device)).cpu()
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-7)
+    out1 = l2_norm(a.to(device)).cpu()
+    assert torch.allclose(out1, a / a.norm(dim=1, keepdim=True), rtol=1e-5, atol=1e-7)
+
+
+def test_l2norm_zero_row_is_nan(device):
+    """No epsilon in the reference (face_model.py:19-22): 0/0 -> NaN, other rows unaffected."""
+    from face_recognition_amd.face_model import l2_norm
+    x = torch.ones((2, 512), device=device)
+    x[0] = 0
+    y = l2_norm(x).cpu()
+    assert torch.isnan(y[0]).all() and torch.allclose(y[1].norm(), torch.tensor(1.0))
+
+
+def test_bad_arguments_report_errors(device):
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.mfn_create(C.byref(h), 0, 500, _lib.FRA_F16) != 0
+    assert b"embedding_size" in lib.fra_last_error()
+    assert lib.mfn_create(C.byref(h), 0, 512, _lib.FRA_F32) != 0
+    assert lib.mfn_create(C.byref(h), 99, 512, _lib.FRA_F16) != 0
+    assert lib.mfn_create(C.byref(h), 0, 512, _lib.FRA_F16) == 0
+    out = torch.empty(4, device=device)
+    rc = lib.mfn_forward(h, out.data_ptr(), 1, out.data_ptr(), out.data_ptr(), 4, None)
+    assert rc == 2 and b"before mfn_load_weights" in lib.fra_last_error()
+    lib.mfn_destroy(h)
+    assert lib.mfn_op_pw(_lib.FRA_F16, out.data_ptr(), out.data_ptr(), out.data_ptr(), None, None, out.data_ptr(), 10,
+                         96, 64, None) != 0
+    assert lib.mfn_op_dw3x3(_lib.FRA_F16, out.data_ptr(), out.data_ptr(), out.data_ptr(), None, out.data_ptr(), 1, 10,
+                            10, 64, 1, None) != 0
