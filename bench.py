@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one MobileFaceNet forward over a batch of 1024 synthetic 112x112 crops per GPU
+(BASELINE.json configs[1]); inputs are resident in HBM before the timed region; the embedding path
+is data parallel with no collective, so N GPUs process N batches per step (weak scaling).
+Rank 0 prints ONE JSON line.  Besides the headline faces/s it carries
+  roofline      -- the forward's dominant kernel: algorithmic bytes / measured duration vs 8 TB/s
+  cpu_baseline  -- the CPU oracle (un-fused fp32 PyTorch graph) timed on this host's cores
+  search        -- 1:N top-5 search, 10k queries against a row-sharded fp16 gallery
+                   (per-shard top-5 -> one all-gather -> merge), queries/s and MFMA fraction
+  kernels       -- per-kernel-class time, bytes and FLOPs of one forward
+  latency_us    -- small-batch forward latency
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from face_recognition_amd import layers, synthetic  # noqa: E402
+from face_recognition_amd.face_model import MobileFaceNet  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, datasheet
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA, datasheet
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="crops per GPU per step")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--chunk", type=int, default=-1, help="batch slice size inside the library (-1 = tuned default)")
+    ap.add_argument("--gallery-rows", type=int, default=100_000_000, help="rows of the WHOLE gallery (sharded over GPUs)")
+    ap.add_argument("--queries", type=int, default=10_000)
+    ap.add_argument("--search-steps", type=int, default=3)
+    ap.add_argument("--no-search", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def kernel_label(name, kind, dt):
+    """Name of the device kernel an op runs, as rocprofv3 prints it (template arguments included)."""
+    T = "_Float16" if dt == "f16" else "__bf16"
+    for c in layers.all_convs():
+        if c.prefix == name:
+            if kind == "pw":
+                bm = 64 if c.cin == 512 else 128
+                nt = 2 if c.cout % 128 == 0 else 1
+                return f"pw_gemm_kernel<{T}, {c.cin}, {bm}, {nt}>"
+            if kind == "dw3x3":
+                return f"dw3x3_kernel<{T}, {c.stride}>"
+    return {"stem": f"stem_kernel<{T}>", "gdconv7": f"gdconv7_kernel<{T}>", "linear": f"linear_l2norm_kernel<{T}, 4>"}[kind]
+
+
+def per_kernel_profile(net, x, reps, dt):
+    """Average per-op milliseconds (HIP events on the launch stream, inside the library), grouped by kernel."""
+    acc = None
+    for _ in range(reps):
+        _, ms, table = net.forward_timed(x)
+        acc = ms if acc is None else acc + ms
+    ms = acc / reps
+    B = x.shape[0]
+    groups = {}
+    for (name, kind, flops, nbytes), t in zip(table, ms):
+        g = groups.setdefault(kernel_label(name, kind, dt), dict(kind=kind, launches=0, ms=0.0, bytes=0.0, flops=0.0))
+        g["launches"] += 1
+        g["ms"] += float(t)
+        g["bytes"] += nbytes * B
+        g["flops"] += flops * B
+    return groups, float(ms.sum())
+
+
+def cpu_baseline(seconds):
+    """The CPU oracle on this host: batches of 32 crops, fp32, un-fused graph, for about `seconds`."""
+    from oracle import mobilefacenet_ref
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(1, 512).items()}
+    x = torch.from_numpy(synthetic.make_crops(32, 0))
+    for _ in range(2):
+        mobilefacenet_ref.forward(sd, x)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        mobilefacenet_ref.forward(sd, x)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 400:
+            break
+    return {"value": round(32 * n / el, 1), "unit": "faces/s", "cores": threads, "kind": "port",
+            "sample": f"{n} batches of 32 crops (fp32 un-fused PyTorch graph of the oracle) in {el:.1f} s; "
+                      f"host has {os.cpu_count()} logical CPUs"}
+
+
+CHUNK_ROWS = 1 << 18  # the synthetic gallery is defined in global chunks of 262,144 rows
+
+
+def gallery_chunk(c, dev):
+    """Rows [c*CHUNK_ROWS, (c+1)*CHUNK_ROWS) of the logical gallery: unit-norm N(0,I), a function of c only,
+    so every sharding of the gallery holds the same rows."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234567 + c)
+    r = torch.randn((CHUNK_ROWS, 512), generator=g, device=dev, dtype=torch.float32)
+    return r / r.norm(dim=1, keepdim=True)
+
+
+def run_search(args, rank, world, dev, dist_mod):
+    from face_recognition_amd.facebank import Gallery
+    from face_recognition_amd.sharded import ShardedGallery, shard_bounds
+    total = args.gallery_rows
+    b, e = shard_bounds(total, world, rank)
+    gal = Gallery(None, n=e - b, d=512, store="f16", device=dev, index_base=b)
+    t0 = time.perf_counter()
+    c0, c1 = b // CHUNK_ROWS, (e - 1) // CHUNK_ROWS
+    for c in range(c0, c1 + 1):
+        rows = gallery_chunk(c, dev)
+        lo, hi = max(b, c * CHUNK_ROWS), min(e, (c + 1) * CHUNK_ROWS)
+        gal.fill(lo - b, rows[lo - c * CHUNK_ROWS: hi - c * CHUNK_ROWS])
+    del rows
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    # queries: half planted near rows of chunk 0 (true nearest row known), half random; same on every rank
+    Q = args.queries
+    first = gallery_chunk(0, dev)[: min(CHUNK_ROWS, total)]
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    pick = torch.randint(0, first.shape[0], (Q // 2,), generator=g, device=dev)
+    noise = torch.randn((Q // 2, 512), generator=g, device=dev)
+    noise = noise / noise.norm(dim=1, keepdim=True)
+    planted = first[pick] + float(np.sqrt(1 / 0.7 ** 2 - 1)) * noise
+    rnd = torch.randn((Q - Q // 2, 512), generator=g, device=dev)
+    q = torch.cat([planted, rnd])
+    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    del first
+    sg = ShardedGallery(total, gal.search)
+    d, i = sg.search(q, 5)          # warm-up + correctness of the planted half
+    torch.cuda.synchronize()
+    hit = float((i[: Q // 2, 0].to(torch.int64) == pick).float().mean())
+    if world > 1:
+        dist_mod.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.search_steps):
+        d, i = sg.search(q, 5)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist_mod.barrier()
+    el = torch.tensor([time.perf_counter() - t0], device=dev)
+    if world > 1:
+        dist_mod.all_reduce(el, op=dist_mod.ReduceOp.MAX)
+    el = float(el) / args.search_steps
+    flops = 2.0 * 512 * Q * total
+    gal.close()
+    return {"metric": "1:N top-5 queries/sec", "value": round(Q / el, 1), "unit": "queries/s", "queries": Q,
+            "gallery_rows": total, "rows_per_gpu": e - b, "k": 5, "gallery_dtype": "f16", "ms_per_batch": round(el * 1e3, 3),
+            "scaling": "strong", "planted_top1_hit_rate": round(hit, 5), "gallery_build_s": round(build_s, 2),
+            "merge": "RCCL all_gather + fb_merge_topk" if world > 1 else "none (1 shard)",
+            "roofline": {"bound": "mfma", "achieved": round(flops / el / 1e12, 2), "peak": MFMA_PEAK_TFLOPS * world,
+                         "unit": "TFLOP/s", "frac": round(flops / el / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
+                         "traffic": None}}
+
+
+def latency(net, dev):
+    out = {}
+    for B in (1, 8):
+        x = torch.rand((B, 3, 112, 112), device=dev) * 2 - 1
+        for _ in range(20):
+            net(x)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(200):
+            t0 = time.perf_counter()
+            net(x)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts = np.sort(np.array(ts)) * 1e6
+        out[f"forward_b{B}"] = {"p50": round(float(ts[len(ts) // 2]), 1), "p99": round(float(ts[int(len(ts) * 0.99)]), 1)}
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    sd = synthetic.make_state_dict(1, 512)
+    net = MobileFaceNet(512, act_dtype=args.dtype)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    net = net.to(dev).eval()
+    if args.chunk >= 0:
+        net.set_batch_chunk(args.chunk)
+    B = args.batch
+    g = torch.Generator(device=dev)
+    g.manual_seed(1000 + rank)
+    x = (torch.randint(0, 256, (B, 3, 112, 112), generator=g, device=dev).float() / 255.0 - 0.5) / 0.5
+
+    for _ in range(args.warmup):
+        y = net(x)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = net(x)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = float(el)
+    assert bool(torch.isfinite(y).all()) and abs(float(y[0].norm()) - 1.0) < 1e-3
+    faces_per_s = world * B * args.steps / el
+
+    result = {
+        "metric": "aligned faces/sec embedded (MobileFaceNet forward)", "value": round(faces_per_s, 1), "unit": "faces/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "MobileFaceNet(512) forward, 1024 synthetic 112x112 crops per GPU per step, seeded "
+                               "random-init weights with non-trivial BatchNorm/PReLU (BASELINE configs[1]); "
+                               "data-parallel embedding, no collective",
+                   "batch_per_gpu": B, "global_batch": B * world, "input": "f32 NCHW resident in HBM",
+                   "output": "f32 [B,512] L2-normalised", "parallelism": f"dp{world}",
+                   "batch_chunk": net._batch_chunk},
+        "flops_per_face": 2 * layers.macs_per_face(512),
+        "forward_tflops": round(faces_per_s * 2 * layers.macs_per_face(512) / 1e12, 2),
+    }
+
+    if rank == 0:
+        groups, total_ms = per_kernel_profile(net, x, 3, args.dtype)
+        dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+        gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dom_name,
+                              "launches_per_step": dom["launches"],
+                              "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                              "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
+                              "share_of_forward": round(dom["ms"] / total_ms, 3)}
+        result["kernels"] = {k: {"kind": v["kind"], "launches": v["launches"], "ms": round(v["ms"], 4),
+                                 "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                 "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in groups.items()}
+        result["sum_kernel_ms"] = round(total_ms, 4)
+        if not args.no_latency:
+            result["latency_us"] = latency(net, dev)
+    if not args.no_search:
+        s = run_search(args, rank, world, dev, dist)
+        if rank == 0:
+            result["search"] = s
+    if rank == 0 and world == 1 and not args.no_cpu:
+        result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()
