@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--gallery-rows", type=int, default=100_000_000, help="rows of the WHOLE gallery (sharded over GPUs)")
     ap.add_argument("--queries", type=int, default=10_000)
     ap.add_argument("--search-steps", type=int, default=3)
+    ap.add_argument("--unfused", action="store_true", help="one kernel per conv instead of one per block")
     ap.add_argument("--no-search", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
@@ -56,6 +57,9 @@ def parse():
 def kernel_label(name, kind, dt):
     """Name of the device kernel an op runs, as rocprofv3 prints it (template arguments included)."""
     T = "_Float16" if dt == "f16" else "__bf16"
+    if kind == "block":
+        b = next(b for b in layers.BLOCKS if b.prefix == name)
+        return f"block_kernel<{T}, {b.cin}, {b.cexp}, {b.cout}, {b.hin}, {b.stride}>"
     for c in layers.all_convs():
         if c.prefix == name:
             if kind == "pw":
@@ -217,6 +221,8 @@ def main():
     net = net.to(dev).eval()
     if args.chunk >= 0:
         net.set_batch_chunk(args.chunk)
+    if args.unfused:
+        net.set_fused(False)
     B = args.batch
     g = torch.Generator(device=dev)
     g.manual_seed(1000 + rank)
@@ -250,7 +256,7 @@ def main():
                                "data-parallel embedding, no collective",
                    "batch_per_gpu": B, "global_batch": B * world, "input": "f32 NCHW resident in HBM",
                    "output": "f32 [B,512] L2-normalised", "parallelism": f"dp{world}",
-                   "batch_chunk": net._batch_chunk},
+                   "batch_chunk": net._batch_chunk, "fused_blocks": net._fused},
         "flops_per_face": 2 * layers.macs_per_face(512),
         "forward_tflops": round(faces_per_s * 2 * layers.macs_per_face(512) / 1e12, 2),
     }

@@ -30,6 +30,7 @@ SIGNATURES = {
     "mfn_load_weights": (_I, [_P, C.POINTER(TensorDesc), _I]),
     "mfn_workspace_bytes": (_I, [_P, _I, C.POINTER(C.c_size_t)]),
     "mfn_set_batch_chunk": (_I, [_P, _I]),
+    "mfn_set_fused": (_I, [_P, _I]),
     "mfn_forward": (_I, [_P, _P, _I, _P, _P, C.c_size_t, _P]),
     "mfn_forward_timed": (_I, [_P, _P, _I, _P, _P, C.c_size_t, _P, C.POINTER(C.c_float), _I]),
     "mfn_op_count": (_I, [_P]),
@@ -40,6 +41,7 @@ SIGNATURES = {
     "mfn_op_stem": (_I, [_I, _P, _P, _P, _P, _P, _I, _P]),
     "mfn_op_dw3x3": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mfn_op_pw": (_I, [_I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "mfn_op_block": (_I, [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "mfn_op_gdconv7": (_I, [_I, _P, _P, _P, _P, _I, _I, _P]),
     "mfn_op_linear_l2norm": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fb_create": (_I, [C.POINTER(_P), _I, _P, _I, _L, _I, _I, _L]),

@@ -78,6 +78,22 @@ int launch_linear_l2norm(int dt, const void* in, const void* w, const float* bia
                          hipStream_t s);
 // out = l2norm(a + b) row-wise (b may be nullptr: plain l2norm), f32 [B,E]
 int launch_add_l2norm(const float* a, const float* b, float* out, int B, int E, hipStream_t s);
+// fused inverted-residual block (expand 1x1 + PReLU, depthwise 3x3 + PReLU, project 1x1, optional shortcut).
+// "p" arrays are indexed by expanded channel in the permuted order perm_pos() defines.
+struct BlockParams {
+    int cin, cexp, cout, h, stride, residual;
+    const void* w1;     // T [cexp][cin], rows in natural channel order, BN folded
+    const float* b1p;   // [cexp] permuted
+    const float* s1p;   // [cexp] permuted PReLU slopes
+    const void* w2p;    // T [9][cexp] permuted, tap-major
+    const float* b2p;
+    const float* s2p;
+    const void* w3p;    // T [cout][cexp], columns permuted
+    const float* b3;    // [cout]
+};
+// position of natural expanded channel c = 16g + 8a + 4h + i in the permuted order: 16g + 8h + 4a + i
+inline int perm_pos(int c) { return (c & ~15) | ((c & 4) << 1) | ((c & 8) >> 1) | (c & 3); }
+int launch_block(int dt, const BlockParams& p, const void* x, void* out, int B, hipStream_t s);
 // T NHWC [n] -> f32 (debug taps)
 int launch_to_f32(int dt, const void* in, float* out, int64_t n, hipStream_t s);
 

@@ -13,7 +13,7 @@ namespace fra {
 
 static const double kBnEps = 1e-5;  // torch BatchNorm default, face_model.py:30,42,92
 
-enum OpKind { OP_STEM = 0, OP_DW = 1, OP_PW = 2, OP_GDCONV = 3, OP_LINEAR = 4 };
+enum OpKind { OP_STEM = 0, OP_DW = 1, OP_PW = 2, OP_GDCONV = 3, OP_LINEAR = 4, OP_BLOCK = 5 };
 // per-image activation buffers inside the workspace
 enum Buf { BUF_X = -1, BUF_P0 = 0, BUF_P1 = 1, BUF_E = 2, BUF_D = 3, BUF_V = 4, BUF_OUT = 5, NBUF = 5 };
 static const int64_t kBufElems[NBUF] = {56 * 56 * 64, 56 * 56 * 64, 56 * 56 * 128, 28 * 28 * 128, 512};
@@ -30,6 +30,11 @@ struct Op {
     const float* slope = nullptr;
     size_t w_off = 0, bias_off = 0, slope_off = 0;  // arena offsets
     double flops = 0, bytes = 0;                    // per image
+    // OP_BLOCK only: expanded width, shortcut flag, arena offsets of the eight parameter arrays
+    int cexp = 0;
+    bool residual = false;
+    size_t blk_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // w1, b1p, s1p, w2p, b2p, s2p, w3p, b3
+    BlockParams bp = {};
 };
 
 static const int NO_RESID = -100;
@@ -42,7 +47,11 @@ struct mfn_handle {
     int dt = fra::ACT_F16;
     int chunk = 0;
     bool loaded = false;
-    std::vector<fra::Op> ops;
+    bool fused = true;                 // run inverted-residual blocks as one kernel each
+    std::vector<fra::Op> ops_plain;    // one kernel per conv
+    std::vector<fra::Op> ops_fused;    // one kernel per block
+    std::vector<fra::Op>& ops() { return fused ? ops_fused : ops_plain; }
+    const std::vector<fra::Op>& ops() const { return fused ? ops_fused : ops_plain; }
     void* arena = nullptr;
     size_t arena_bytes = 0;
 };
@@ -51,8 +60,8 @@ namespace fra {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static void build_ops(mfn_handle* h) {
-    std::vector<Op>& ops = h->ops;
+static void build_ops(mfn_handle* h, bool fused) {
+    std::vector<Op>& ops = fused ? h->ops_fused : h->ops_plain;
     const int es = 2;  // bytes per activation / weight element
     auto add = [&](OpKind k, const std::string& name, int in, int out, int resid, int cin, int cout, int hin,
                    int hout, int stride, bool prelu) {
@@ -82,6 +91,7 @@ static void build_ops(mfn_handle* h) {
                 o.flops = 2.0 * cin * cout;
                 o.bytes = cin * es + cout * 4.0 + (double)cin * cout * es;
                 break;
+            case OP_BLOCK: break;  // filled in by the caller
         }
         ops.push_back(o);
     };
@@ -92,6 +102,17 @@ static void build_ops(mfn_handle* h) {
     auto block = [&](const std::string& p, int cin, int cexp, int cout, int stride, bool res, int hin) {
         const int hout = (hin + 2 - 3) / stride + 1;
         const int other = cur == BUF_P0 ? BUF_P1 : BUF_P0;
+        if (fused) {                                                                        // face_model.py:55-65
+            add(OP_BLOCK, p, cur, other, NO_RESID, cin, cout, hin, hout, stride, false);
+            Op& o = ops.back();
+            o.cexp = cexp;
+            o.residual = res;
+            const double pin = (double)hin * hin, pout = (double)hout * hout;
+            o.flops = 2.0 * (pin * cin * cexp + pout * cexp * 9 + pout * cexp * cout);
+            o.bytes = (pin * cin + pout * cout) * es + ((double)cin * cexp + 9.0 * cexp + (double)cexp * cout) * es;
+            cur = other;
+            return;
+        }
         add(OP_PW, p + ".conv", cur, BUF_E, NO_RESID, cin, cexp, hin, hin, 1, true);        // face_model.py:51
         add(OP_DW, p + ".conv_dw", BUF_E, BUF_D, NO_RESID, cexp, cexp, hin, hout, stride, true);  // :52
         add(OP_PW, p + ".project", BUF_D, other, res ? cur : NO_RESID, cexp, cout, hout, hout, 1, false);  // :53,62
@@ -181,9 +202,19 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
         m[key] = v;
     }
     const int dt = h->dt;
-    // plan the arena
+    // plan the arena (both schedules keep their own copies; 5 MB in all)
     size_t off = 0;
-    for (Op& o : h->ops) {
+    std::vector<Op*> all;
+    for (Op& o : h->ops_plain) all.push_back(&o);
+    for (Op& o : h->ops_fused) all.push_back(&o);
+    for (Op* op : all) {
+        Op& o = *op;
+        if (o.kind == OP_BLOCK) {
+            const size_t sz[8] = {(size_t)o.cexp * o.cin * 2, (size_t)o.cexp * 4, (size_t)o.cexp * 4, 9 * (size_t)o.cexp * 2,
+                                  (size_t)o.cexp * 4,         (size_t)o.cexp * 4, (size_t)o.cout * o.cexp * 2, (size_t)o.cout * 4};
+            for (int i = 0; i < 8; ++i) { o.blk_off[i] = off; off = align_up(off + sz[i], 256); }
+            continue;
+        }
         size_t wbytes = 0;
         switch (o.kind) {
             case OP_STEM: wbytes = 27 * 64 * 4; break;
@@ -191,17 +222,55 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
             case OP_PW: wbytes = (size_t)o.cin * o.cout * 2; break;
             case OP_GDCONV: wbytes = 49 * (size_t)o.cout * 2; break;
             case OP_LINEAR: wbytes = (size_t)o.cin * o.cout * 2; break;
+            case OP_BLOCK: break;
         }
         o.w_off = off; off = align_up(off + wbytes, 256);
         o.bias_off = off; off = align_up(off + (size_t)o.cout * 4, 256);
         o.slope_off = off; off = align_up(off + (size_t)o.cout * 4, 256);
     }
     std::vector<unsigned char> host(off, 0);
-    for (Op& o : h->ops) {
+    for (Op* op : all) {
+        Op& o = *op;
         std::vector<double> scale, shift;
         const float* w = nullptr;
         int rc;
         const int C = o.cout;
+        if (o.kind == OP_BLOCK) {
+            // expand (natural row order), depthwise and project columns in the permuted channel order
+            const int CE = o.cexp, CI = o.cin;
+            const float* a;
+            uint16_t* w1 = reinterpret_cast<uint16_t*>(host.data() + o.blk_off[0]);
+            float* b1p = reinterpret_cast<float*>(host.data() + o.blk_off[1]);
+            float* s1p = reinterpret_cast<float*>(host.data() + o.blk_off[2]);
+            uint16_t* w2p = reinterpret_cast<uint16_t*>(host.data() + o.blk_off[3]);
+            float* b2p = reinterpret_cast<float*>(host.data() + o.blk_off[4]);
+            float* s2p = reinterpret_cast<float*>(host.data() + o.blk_off[5]);
+            uint16_t* w3p = reinterpret_cast<uint16_t*>(host.data() + o.blk_off[6]);
+            float* b3 = reinterpret_cast<float*>(host.data() + o.blk_off[7]);
+            if ((rc = fetch(m, o.name + ".conv.conv.weight", (int64_t)CE * CI, &w))) return rc;
+            if ((rc = bn_fold(m, o.name + ".conv.bn", CE, scale, shift))) return rc;
+            if ((rc = fetch(m, o.name + ".conv.prelu.weight", CE, &a))) return rc;
+            for (int e = 0; e < CE; ++e) {
+                for (int k = 0; k < CI; ++k) w1[(size_t)e * CI + k] = to16(dt, (float)(w[(size_t)e * CI + k] * scale[e]));
+                b1p[perm_pos(e)] = (float)shift[e];
+                s1p[perm_pos(e)] = a[e];
+            }
+            if ((rc = fetch(m, o.name + ".conv_dw.conv.weight", (int64_t)CE * 9, &w))) return rc;
+            if ((rc = bn_fold(m, o.name + ".conv_dw.bn", CE, scale, shift))) return rc;
+            if ((rc = fetch(m, o.name + ".conv_dw.prelu.weight", CE, &a))) return rc;
+            for (int e = 0; e < CE; ++e) {
+                for (int t = 0; t < 9; ++t) w2p[(size_t)t * CE + perm_pos(e)] = to16(dt, (float)(w[(size_t)e * 9 + t] * scale[e]));
+                b2p[perm_pos(e)] = (float)shift[e];
+                s2p[perm_pos(e)] = a[e];
+            }
+            if ((rc = fetch(m, o.name + ".project.conv.weight", (int64_t)C * CE, &w))) return rc;
+            if ((rc = bn_fold(m, o.name + ".project.bn", C, scale, shift))) return rc;
+            for (int n = 0; n < C; ++n) {
+                for (int e = 0; e < CE; ++e) w3p[(size_t)n * CE + perm_pos(e)] = to16(dt, (float)(w[(size_t)n * CE + e] * scale[n]));
+                b3[n] = (float)shift[n];
+            }
+            continue;
+        }
         float* bias = reinterpret_cast<float*>(host.data() + o.bias_off);
         float* slope = reinterpret_cast<float*>(host.data() + o.slope_off);
         if (o.kind == OP_LINEAR) {
@@ -246,7 +315,22 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
         h->arena_bytes = off;
     }
     FRA_HIP(hipMemcpy(h->arena, host.data(), off, hipMemcpyHostToDevice));
-    for (Op& o : h->ops) {
+    for (Op* op : all) {
+        Op& o = *op;
+        char* base = static_cast<char*>(h->arena);
+        if (o.kind == OP_BLOCK) {
+            BlockParams& b = o.bp;
+            b.cin = o.cin; b.cexp = o.cexp; b.cout = o.cout; b.h = o.hin; b.stride = o.stride; b.residual = o.residual;
+            b.w1 = base + o.blk_off[0];
+            b.b1p = reinterpret_cast<const float*>(base + o.blk_off[1]);
+            b.s1p = reinterpret_cast<const float*>(base + o.blk_off[2]);
+            b.w2p = base + o.blk_off[3];
+            b.b2p = reinterpret_cast<const float*>(base + o.blk_off[4]);
+            b.s2p = reinterpret_cast<const float*>(base + o.blk_off[5]);
+            b.w3p = base + o.blk_off[6];
+            b.b3 = reinterpret_cast<const float*>(base + o.blk_off[7]);
+            continue;
+        }
         o.w = static_cast<char*>(h->arena) + o.w_off;
         o.bias = reinterpret_cast<const float*>(static_cast<char*>(h->arena) + o.bias_off);
         o.slope = o.prelu ? reinterpret_cast<const float*>(static_cast<char*>(h->arena) + o.slope_off) : nullptr;
@@ -288,6 +372,8 @@ static int run_op(const mfn_handle* h, const Op& o, const float* x, float* out, 
             return launch_gdconv7(h->dt, buf(o.in), o.w, o.bias, buf(o.out), b, o.cout, s);
         case OP_LINEAR:
             return launch_linear_l2norm(h->dt, buf(o.in), o.w, o.bias, out, b, o.cin, o.cout, s);
+        case OP_BLOCK:
+            return launch_block(h->dt, o.bp, buf(o.in), buf(o.out), b, s);
     }
     return FRA_ERR_ARG;
 }
@@ -309,7 +395,7 @@ static int forward(mfn_handle* h, const float* x, int B, float* out, void* ws, s
                    float* op_ms, int n_ops_timed) {
     int rc = check_forward_args(h, x, B, out, ws, ws_bytes);
     if (rc) return rc;
-    const int nops = (int)h->ops.size();
+    const int nops = (int)h->ops().size();
     const int sl = slice_size(h, B);
     std::vector<hipEvent_t> ev;
     if (op_ms) {
@@ -325,7 +411,7 @@ static int forward(mfn_handle* h, const float* x, int B, float* out, void* ws, s
         float* os = out + (size_t)b0 * h->E;
         if (op_ms) FRA_HIP(hipEventRecord(ev[0], s));
         for (int i = 0; i < nops; ++i) {
-            rc = run_op(h, h->ops[i], xs, os, static_cast<char*>(ws), p, b, s);
+            rc = run_op(h, h->ops()[i], xs, os, static_cast<char*>(ws), p, b, s);
             if (rc) return rc;
             if (op_ms) FRA_HIP(hipEventRecord(ev[i + 1], s));
         }
@@ -362,7 +448,8 @@ int mfn_create(mfn_handle** out, int device, int embedding_size, int act_dtype) 
     h->device = device;
     h->E = embedding_size;
     h->dt = act_dtype;
-    build_ops(h);
+    build_ops(h, false);
+    build_ops(h, true);
     *out = h;
     return FRA_OK;
 }
@@ -384,6 +471,12 @@ int mfn_set_batch_chunk(mfn_handle* h, int images) {
     return FRA_OK;
 }
 
+int mfn_set_fused(mfn_handle* h, int fused) {
+    FRA_REQUIRE(h != nullptr, FRA_ERR_ARG, "mfn_set_fused: null handle");
+    h->fused = fused != 0;
+    return FRA_OK;
+}
+
 int mfn_forward(mfn_handle* h, const float* x, int B, float* out, void* ws, size_t ws_bytes, fra_stream stream) {
     return forward(h, x, B, out, ws, ws_bytes, (hipStream_t)stream, nullptr, 0);
 }
@@ -394,11 +487,11 @@ int mfn_forward_timed(mfn_handle* h, const float* x, int B, float* out, void* ws
     return forward(h, x, B, out, ws, ws_bytes, (hipStream_t)stream, op_ms, n_ops);
 }
 
-int mfn_op_count(const mfn_handle* h) { return h ? (int)h->ops.size() : -1; }
+int mfn_op_count(const mfn_handle* h) { return h ? (int)h->ops().size() : -1; }
 
 int mfn_op_info(const mfn_handle* h, int op, char* name, int name_cap, int* kind, double* flops, double* bytes) {
-    FRA_REQUIRE(h && op >= 0 && op < (int)h->ops.size(), FRA_ERR_ARG, "mfn_op_info: bad argument");
-    const Op& o = h->ops[op];
+    FRA_REQUIRE(h && op >= 0 && op < (int)h->ops().size(), FRA_ERR_ARG, "mfn_op_info: bad argument");
+    const Op& o = h->ops()[op];
     if (name && name_cap > 0) {
         strncpy(name, o.name.c_str(), name_cap - 1);
         name[name_cap - 1] = 0;
@@ -413,16 +506,16 @@ int mfn_debug_prefix(mfn_handle* h, const float* x, int B, int n_ops, float* out
                      void* ws, size_t ws_bytes, fra_stream stream) {
     int rc = check_forward_args(h, x, B, out_f32, ws, ws_bytes);
     if (rc) return rc;
-    FRA_REQUIRE(n_ops >= 1 && n_ops < (int)h->ops.size(), FRA_ERR_ARG,
-                "mfn_debug_prefix: n_ops %d not in [1,%d)", n_ops, (int)h->ops.size());
+    FRA_REQUIRE(n_ops >= 1 && n_ops < (int)h->ops().size(), FRA_ERR_ARG,
+                "mfn_debug_prefix: n_ops %d not in [1,%d)", n_ops, (int)h->ops().size());
     FRA_REQUIRE(slice_size(h, B) == B, FRA_ERR_STATE, "mfn_debug_prefix: batch chunking must be off");
     const WsPlan p = plan_ws(B);
     hipStream_t s = (hipStream_t)stream;
     for (int i = 0; i < n_ops; ++i) {
-        rc = run_op(h, h->ops[i], x, nullptr, static_cast<char*>(ws), p, B, s);
+        rc = run_op(h, h->ops()[i], x, nullptr, static_cast<char*>(ws), p, B, s);
         if (rc) return rc;
     }
-    const Op& o = h->ops[n_ops - 1];
+    const Op& o = h->ops()[n_ops - 1];
     const int64_t per = (int64_t)o.hout * o.hout * o.cout;
     if (numel_per_image) *numel_per_image = per;
     return launch_to_f32(h->dt, static_cast<char*>(ws) + p.off[o.out], out_f32, per * B, s);
@@ -453,6 +546,14 @@ int mfn_op_dw3x3(int dtype, const void* in, const void* w, const float* bias, co
 int mfn_op_pw(int dtype, const void* in, const void* w, const float* bias, const float* slope, const void* resid,
               void* out, int64_t M, int K, int N, fra_stream stream) {
     return launch_pw(dtype, in, w, bias, slope, resid, out, M, K, N, (hipStream_t)stream);
+}
+int mfn_op_block(int dtype, int cin, int cexp, int cout, int h, int stride, int residual, const void* x,
+                 const void* w1, const float* b1p, const float* s1p, const void* w2p, const float* b2p,
+                 const float* s2p, const void* w3p, const float* b3, void* out, int B, fra_stream stream) {
+    BlockParams p;
+    p.cin = cin; p.cexp = cexp; p.cout = cout; p.h = h; p.stride = stride; p.residual = residual;
+    p.w1 = w1; p.b1p = b1p; p.s1p = s1p; p.w2p = w2p; p.b2p = b2p; p.s2p = s2p; p.w3p = w3p; p.b3 = b3;
+    return launch_block(dtype, p, x, out, B, (hipStream_t)stream);
 }
 int mfn_op_gdconv7(int dtype, const void* in, const void* w, const float* bias, void* out, int B, int C,
                    fra_stream stream) {

@@ -115,6 +115,7 @@ class MobileFaceNet(nn.Module):
         self._dirty = True
         self._workspace: Optional[torch.Tensor] = None
         self._batch_chunk = 0
+        self._fused = True
 
     # ---- weight life cycle --------------------------------------------------------------------
     def _apply(self, fn, *args, **kwargs):
@@ -142,6 +143,12 @@ class MobileFaceNet(nn.Module):
         if self._handle is not None:
             _lib.check(_lib.load().mfn_set_batch_chunk(self._handle, self._batch_chunk), "mfn_set_batch_chunk")
 
+    def set_fused(self, fused: bool) -> None:
+        """True (default): one kernel per inverted-residual block; False: one kernel per conv."""
+        self._fused = bool(fused)
+        if self._handle is not None:
+            _lib.check(_lib.load().mfn_set_fused(self._handle, int(self._fused)), "mfn_set_fused")
+
     def _ensure_handle(self, device: torch.device):
         lib = _lib.load()
         if self._handle is not None and self._handle_device != device:
@@ -154,6 +161,7 @@ class MobileFaceNet(nn.Module):
                        "mfn_create")
             self._handle, self._handle_device, self._dirty = h.value, device, True
             _lib.check(lib.mfn_set_batch_chunk(self._handle, self._batch_chunk), "mfn_set_batch_chunk")
+            _lib.check(lib.mfn_set_fused(self._handle, int(self._fused)), "mfn_set_fused")
         if self._dirty:
             sd = self.state_dict()
             keep, descs = [], (_lib.TensorDesc * len(sd))()
@@ -230,7 +238,7 @@ class MobileFaceNet(nn.Module):
         lib = _lib.load()
         if self._handle is None:
             raise RuntimeError("op_table: run a forward first")
-        kinds = ["stem", "dw3x3", "pw", "gdconv7", "linear"]
+        kinds = ["stem", "dw3x3", "pw", "gdconv7", "linear", "block"]
         rows = []
         for i in range(lib.mfn_op_count(self._handle)):
             name = C.create_string_buffer(96)

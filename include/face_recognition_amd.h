@@ -66,6 +66,10 @@ int mfn_workspace_bytes(const mfn_handle* h, int max_batch, size_t* bytes);
  * layer-to-layer activations inside the 256 MB Infinity Cache. */
 int mfn_set_batch_chunk(mfn_handle* h, int images);
 
+/* fused != 0 (the default): every inverted-residual block (expand, depthwise, project, shortcut) runs
+ * as one kernel; 0: one kernel per conv.  Changes mfn_op_count / mfn_op_info / mfn_debug_prefix. */
+int mfn_set_fused(mfn_handle* h, int fused);
+
 /* x: dev f32 [B,3,112,112] NCHW (BGR, [-1,1]) -> out: dev f32 [B,embedding_size], rows unit L2 norm.
  * Replaces MobileFaceNet.forward: face_model.py:103-129. */
 int mfn_forward(mfn_handle* h, const float* x_nchw, int B, float* out, void* workspace, size_t workspace_bytes,
@@ -76,7 +80,7 @@ int mfn_forward(mfn_handle* h, const float* x_nchw, int B, float* out, void* wor
 int mfn_forward_timed(mfn_handle* h, const float* x_nchw, int B, float* out, void* workspace,
                       size_t workspace_bytes, fra_stream stream, float* op_ms, int n_ops);
 int mfn_op_count(const mfn_handle* h);
-/* kind: 0 stem, 1 depthwise 3x3, 2 pointwise, 3 gdconv 7x7, 4 linear+l2norm.  flops / bytes are the
+/* kind: 0 stem, 1 depthwise 3x3, 2 pointwise, 3 gdconv 7x7, 4 linear+l2norm, 5 fused block.  flops / bytes are the
  * algorithmic work and HBM traffic (inputs + outputs + weights) of the op for ONE image. */
 int mfn_op_info(const mfn_handle* h, int op, char* name, int name_cap, int* kind, double* flops_per_image,
                 double* bytes_per_image);
@@ -100,6 +104,12 @@ int mfn_op_dw3x3(int dtype, const void* in, const void* w9xC, const float* bias,
                  void* out, int B, int H, int W, int C, int stride, fra_stream stream);
 int mfn_op_pw(int dtype, const void* in, const void* wNxK, const float* bias, const float* slope_or_null,
               const void* resid_or_null, void* out, int64_t M, int K, int N, fra_stream stream);
+/* Fused inverted-residual block (face_model.py:55-65).  Arrays indexed by expanded channel on the
+ * depthwise / project side (b1p, s1p, w2p [9][cexp], b2p, s2p, columns of w3p [cout][cexp]) are in
+ * the kernel's permuted channel order: natural channel 16g+8a+4h+i is stored at 16g+8h+4a+i. */
+int mfn_op_block(int dtype, int cin, int cexp, int cout, int h, int stride, int residual, const void* x,
+                 const void* w1, const float* b1p, const float* s1p, const void* w2p, const float* b2p,
+                 const float* s2p, const void* w3p, const float* b3, void* out, int B, fra_stream stream);
 int mfn_op_gdconv7(int dtype, const void* in, const void* w49xC, const float* bias, void* out, int B, int C,
                    fra_stream stream);
 int mfn_op_linear_l2norm(int dtype, const void* in, const void* wExK, const float* bias, float* out, int B, int K,

@@ -102,6 +102,53 @@ def test_pw(device, dt, M, K, N, prelu, resid):
     close(out, ref, rel, f"pw M={M} K={K} N={N}")
 
 
+def _perm(c):
+    """Permuted position of natural expanded channel c = 16g + 8a + 4h + i: 16g + 8h + 4a + i."""
+    return (c & ~15) | ((c & 4) << 1) | ((c & 8) >> 1) | (c & 3)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("cin,cexp,cout,H,stride,res,B", [(64, 128, 64, 56, 2, False, 2), (64, 128, 64, 28, 1, True, 3),
+                                                         (64, 256, 128, 28, 2, False, 2), (128, 256, 128, 14, 1, True, 3),
+                                                         (128, 512, 128, 14, 2, False, 2), (128, 256, 128, 7, 1, True, 5)])
+def test_fused_block(device, dt, cin, cexp, cout, H, stride, res, B):
+    """Fused expand/depthwise/project block against the three torch convs on 16-bit-rounded operands;
+    the intermediate tensors are rounded to the storage type where the kernel rounds them."""
+    tdt, code, rel = DT[dt]
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((B, cin, H, H), generator=g).to(tdt).float()
+    w1 = (torch.randn((cexp, cin), generator=g) / np.sqrt(cin) * 1.3).to(tdt).float()
+    b1, s1 = torch.randn(cexp, generator=g) * 0.2, torch.rand(cexp, generator=g) * 0.3 + 0.1
+    w2 = (torch.randn((cexp, 1, 3, 3), generator=g) * 0.4).to(tdt).float()
+    b2, s2 = torch.randn(cexp, generator=g) * 0.2, torch.rand(cexp, generator=g) * 0.3 + 0.1
+    w3 = (torch.randn((cout, cexp), generator=g) / np.sqrt(cexp)).to(tdt).float()
+    b3 = torch.randn(cout, generator=g) * 0.2
+    e = F.prelu(F.conv2d(x, w1[:, :, None, None], b1), s1).to(tdt).float()
+    d = F.prelu(F.conv2d(e, w2, b2, stride, 1, 1, cexp), s2).to(tdt).float()
+    y = F.conv2d(d, w3[:, :, None, None], b3)
+    if res:
+        y = y + x
+    ref = y.permute(0, 2, 3, 1).contiguous()
+    perm = torch.tensor([_perm(c) for c in range(cexp)])
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(cexp)                # inv[pos] = natural channel stored at pos
+    dev = lambda t: t.contiguous().to(device)    # noqa: E731
+    xd = dev(x.permute(0, 2, 3, 1).to(tdt))
+    w1d, b1d, s1d = dev(w1.to(tdt)), dev(b1[inv]), dev(s1[inv])
+    w2d = dev(w2.reshape(cexp, 9).t()[:, inv].to(tdt))
+    b2d, s2d = dev(b2[inv]), dev(s2[inv])
+    w3d, b3d = dev(w3[:, inv].to(tdt)), dev(b3)
+    Ho = H // stride
+    out = torch.full((B, Ho, Ho, cout), float("nan"), dtype=tdt, device=device)
+    _lib.check(lib.mfn_op_block(code, cin, cexp, cout, H, stride, int(res), xd.data_ptr(), w1d.data_ptr(),
+                                b1d.data_ptr(), s1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), s2d.data_ptr(),
+                                w3d.data_ptr(), b3d.data_ptr(), out.data_ptr(), B, stream(device)), "block")
+    torch.cuda.synchronize()
+    # intermediates are re-rounded, so allow a few output roundings
+    close(out, ref, 3 * rel, f"block {cin}->{cexp}->{cout} H={H} s={stride}")
+
+
 def test_pw_orientation_asymmetric(device):
     """A = identity against an asymmetric weight matrix exposes a transposed output or operand map."""
     lib = _lib.load()

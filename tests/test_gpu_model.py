@@ -75,6 +75,23 @@ def test_batch_independence_and_chunking(hip_model, device):
     assert torch.equal(full, chunked)
 
 
+def test_fused_and_unfused_schedules_agree(hip_model, device, state_dict_np):
+    """One kernel per block vs one kernel per conv: same arithmetic up to summation order."""
+    xn = synthetic.make_crops(3, 21)
+    x = torch.from_numpy(xn).to(device)
+    fused = hip_model(x).cpu().numpy()
+    hip_model.set_fused(False)
+    try:
+        plain = hip_model(x).cpu().numpy()
+        assert len(hip_model.op_table()) == 50
+    finally:
+        hip_model.set_fused(True)
+    assert len(hip_model.op_table()) == 20
+    want = ref.forward_numpy(state_dict_np, xn)
+    assert cosine_rows(fused, want).min() >= COS_BAR and cosine_rows(plain, want).min() >= COS_BAR
+    assert cosine_rows(fused, plain).min() >= 0.99999
+
+
 def test_output_is_fresh_tensor_and_deterministic(hip_model, device):
     x = torch.from_numpy(synthetic.make_crops(3, 8)).to(device)
     a = hip_model(x)
