@@ -94,6 +94,16 @@ struct BlockParams {
 // position of natural expanded channel c = 16g + 8a + 4h + i in the permuted order: 16g + 8h + 4a + i
 inline int perm_pos(int c) { return (c & ~15) | ((c & 4) << 1) | ((c & 8) >> 1) | (c & 3); }
 int launch_block(int dt, const BlockParams& p, const void* x, void* out, int B, hipStream_t s);
+// fused head: stem conv (3->64, 3x3 s2, PReLU) + depthwise 3x3 (64 ch, PReLU); x f32 NCHW -> out T NHWC [B,56,56,64]
+struct StemDwParams {
+    const void* wa;     // T [64][32]: row perm_pos(oc) holds output channel oc, columns = taps (c*9+ky*3+kx), 27..31 zero
+    const float* b1;    // [64] natural order
+    const float* s1;
+    const void* w2;     // T [9][64] tap-major depthwise weights
+    const float* b2;
+    const float* s2;
+};
+int launch_stemdw(int dt, const StemDwParams& p, const float* x, void* out, int B, hipStream_t s);
 // T NHWC [n] -> f32 (debug taps)
 int launch_to_f32(int dt, const void* in, float* out, int64_t n, hipStream_t s);
 

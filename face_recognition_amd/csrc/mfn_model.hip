@@ -13,7 +13,7 @@ namespace fra {
 
 static const double kBnEps = 1e-5;  // torch BatchNorm default, face_model.py:30,42,92
 
-enum OpKind { OP_STEM = 0, OP_DW = 1, OP_PW = 2, OP_GDCONV = 3, OP_LINEAR = 4, OP_BLOCK = 5 };
+enum OpKind { OP_STEM = 0, OP_DW = 1, OP_PW = 2, OP_GDCONV = 3, OP_LINEAR = 4, OP_BLOCK = 5, OP_STEMDW = 6 };
 // per-image activation buffers inside the workspace
 enum Buf { BUF_X = -1, BUF_P0 = 0, BUF_P1 = 1, BUF_E = 2, BUF_D = 3, BUF_V = 4, BUF_OUT = 5, NBUF = 5 };
 static const int64_t kBufElems[NBUF] = {56 * 56 * 64, 56 * 56 * 64, 56 * 56 * 128, 28 * 28 * 128, 512};
@@ -35,6 +35,9 @@ struct Op {
     bool residual = false;
     size_t blk_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // w1, b1p, s1p, w2p, b2p, s2p, w3p, b3
     BlockParams bp = {};
+    // OP_STEMDW only
+    size_t sd_off[6] = {0, 0, 0, 0, 0, 0};          // wa, b1, s1, w2, b2, s2
+    StemDwParams sp = {};
 };
 
 static const int NO_RESID = -100;
@@ -92,12 +95,20 @@ static void build_ops(mfn_handle* h, bool fused) {
                 o.bytes = cin * es + cout * 4.0 + (double)cin * cout * es;
                 break;
             case OP_BLOCK: break;  // filled in by the caller
+            case OP_STEMDW:
+                o.flops = 2.0 * px_out * 64 * 27 + 2.0 * px_out * 64 * 9;
+                o.bytes = px_in * 3 * 4 + px_out * 64 * es + 64 * 32 * es + 9 * 64 * es;
+                break;
         }
         ops.push_back(o);
     };
     // face_model.py:80-81
-    add(OP_STEM, "conv1", BUF_X, BUF_P0, NO_RESID, 3, 64, 112, 56, 2, true);
-    add(OP_DW, "conv2_dw", BUF_P0, BUF_P1, NO_RESID, 64, 64, 56, 56, 1, true);
+    if (fused) {
+        add(OP_STEMDW, "conv2_dw", BUF_X, BUF_P1, NO_RESID, 3, 64, 112, 56, 2, true);
+    } else {
+        add(OP_STEM, "conv1", BUF_X, BUF_P0, NO_RESID, 3, 64, 112, 56, 2, true);
+        add(OP_DW, "conv2_dw", BUF_P0, BUF_P1, NO_RESID, 64, 64, 56, 56, 1, true);
+    }
     int cur = BUF_P1;
     auto block = [&](const std::string& p, int cin, int cexp, int cout, int stride, bool res, int hin) {
         const int hout = (hin + 2 - 3) / stride + 1;
@@ -215,6 +226,11 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
             for (int i = 0; i < 8; ++i) { o.blk_off[i] = off; off = align_up(off + sz[i], 256); }
             continue;
         }
+        if (o.kind == OP_STEMDW) {
+            const size_t sz[6] = {64 * 32 * 2, 256, 256, 9 * 64 * 2, 256, 256};
+            for (int i = 0; i < 6; ++i) { o.sd_off[i] = off; off = align_up(off + sz[i], 256); }
+            continue;
+        }
         size_t wbytes = 0;
         switch (o.kind) {
             case OP_STEM: wbytes = 27 * 64 * 4; break;
@@ -223,6 +239,7 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
             case OP_GDCONV: wbytes = 49 * (size_t)o.cout * 2; break;
             case OP_LINEAR: wbytes = (size_t)o.cin * o.cout * 2; break;
             case OP_BLOCK: break;
+            case OP_STEMDW: break;
         }
         o.w_off = off; off = align_up(off + wbytes, 256);
         o.bias_off = off; off = align_up(off + (size_t)o.cout * 4, 256);
@@ -235,6 +252,33 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
         const float* w = nullptr;
         int rc;
         const int C = o.cout;
+        if (o.kind == OP_STEMDW) {
+            const float* a;
+            uint16_t* wa = reinterpret_cast<uint16_t*>(host.data() + o.sd_off[0]);
+            float* b1 = reinterpret_cast<float*>(host.data() + o.sd_off[1]);
+            float* s1 = reinterpret_cast<float*>(host.data() + o.sd_off[2]);
+            uint16_t* w2 = reinterpret_cast<uint16_t*>(host.data() + o.sd_off[3]);
+            float* b2 = reinterpret_cast<float*>(host.data() + o.sd_off[4]);
+            float* s2 = reinterpret_cast<float*>(host.data() + o.sd_off[5]);
+            if ((rc = fetch(m, "conv1.conv.weight", 64 * 27, &w))) return rc;
+            if ((rc = bn_fold(m, "conv1.bn", 64, scale, shift))) return rc;
+            if ((rc = fetch(m, "conv1.prelu.weight", 64, &a))) return rc;
+            for (int oc = 0; oc < 64; ++oc) {
+                for (int t = 0; t < 32; ++t)
+                    wa[perm_pos(oc) * 32 + t] = to16(dt, t < 27 ? (float)(w[oc * 27 + t] * scale[oc]) : 0.0f);
+                b1[oc] = (float)shift[oc];
+                s1[oc] = a[oc];
+            }
+            if ((rc = fetch(m, "conv2_dw.conv.weight", 64 * 9, &w))) return rc;
+            if ((rc = bn_fold(m, "conv2_dw.bn", 64, scale, shift))) return rc;
+            if ((rc = fetch(m, "conv2_dw.prelu.weight", 64, &a))) return rc;
+            for (int c = 0; c < 64; ++c) {
+                for (int t = 0; t < 9; ++t) w2[t * 64 + c] = to16(dt, (float)(w[c * 9 + t] * scale[c]));
+                b2[c] = (float)shift[c];
+                s2[c] = a[c];
+            }
+            continue;
+        }
         if (o.kind == OP_BLOCK) {
             // expand (natural row order), depthwise and project columns in the permuted channel order
             const int CE = o.cexp, CI = o.cin;
@@ -318,6 +362,15 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
     for (Op* op : all) {
         Op& o = *op;
         char* base = static_cast<char*>(h->arena);
+        if (o.kind == OP_STEMDW) {
+            o.sp.wa = base + o.sd_off[0];
+            o.sp.b1 = reinterpret_cast<const float*>(base + o.sd_off[1]);
+            o.sp.s1 = reinterpret_cast<const float*>(base + o.sd_off[2]);
+            o.sp.w2 = base + o.sd_off[3];
+            o.sp.b2 = reinterpret_cast<const float*>(base + o.sd_off[4]);
+            o.sp.s2 = reinterpret_cast<const float*>(base + o.sd_off[5]);
+            continue;
+        }
         if (o.kind == OP_BLOCK) {
             BlockParams& b = o.bp;
             b.cin = o.cin; b.cexp = o.cexp; b.cout = o.cout; b.h = o.hin; b.stride = o.stride; b.residual = o.residual;
@@ -374,6 +427,8 @@ static int run_op(const mfn_handle* h, const Op& o, const float* x, float* out, 
             return launch_linear_l2norm(h->dt, buf(o.in), o.w, o.bias, out, b, o.cin, o.cout, s);
         case OP_BLOCK:
             return launch_block(h->dt, o.bp, buf(o.in), buf(o.out), b, s);
+        case OP_STEMDW:
+            return launch_stemdw(h->dt, o.sp, x, buf(o.out), b, s);
     }
     return FRA_ERR_ARG;
 }

@@ -80,7 +80,7 @@ int mfn_forward(mfn_handle* h, const float* x_nchw, int B, float* out, void* wor
 int mfn_forward_timed(mfn_handle* h, const float* x_nchw, int B, float* out, void* workspace,
                       size_t workspace_bytes, fra_stream stream, float* op_ms, int n_ops);
 int mfn_op_count(const mfn_handle* h);
-/* kind: 0 stem, 1 depthwise 3x3, 2 pointwise, 3 gdconv 7x7, 4 linear+l2norm, 5 fused block.  flops / bytes are the
+/* kind: 0 stem, 1 depthwise 3x3, 2 pointwise, 3 gdconv 7x7, 4 linear+l2norm, 5 fused block, 6 fused stem + first depthwise.  flops / bytes are the
  * algorithmic work and HBM traffic (inputs + outputs + weights) of the op for ONE image. */
 int mfn_op_info(const mfn_handle* h, int op, char* name, int name_cap, int* kind, double* flops_per_image,
                 double* bytes_per_image);
