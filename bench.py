@@ -80,11 +80,11 @@ def per_kernel_profile(net, x, reps, dt):
     ms = acc / reps
     B = x.shape[0]
     groups = {}
-    for (name, kind, flops, nbytes), t in zip(table, ms):
+    for (name, kind, flops, nbytes, wbytes), t in zip(table, ms):
         g = groups.setdefault(kernel_label(name, kind, dt), dict(kind=kind, launches=0, ms=0.0, bytes=0.0, flops=0.0))
         g["launches"] += 1
         g["ms"] += float(t)
-        g["bytes"] += nbytes * B
+        g["bytes"] += nbytes * B + wbytes
         g["flops"] += flops * B
     return groups, float(ms.sum())
 

@@ -84,10 +84,10 @@ struct BlockParams {
     int cin, cexp, cout, h, stride, residual;
     const void* w1;     // T [cexp][cin], rows in natural channel order, BN folded
     const float* b1p;   // [cexp] permuted
-    const float* s1p;   // [cexp] permuted PReLU slopes
+    const float* s1p;   // [cexp] permuted, PReLU slope MINUS ONE
     const void* w2p;    // T [9][cexp] permuted, tap-major
     const float* b2p;
-    const float* s2p;
+    const float* s2p;   // [cexp] permuted, PReLU slope MINUS ONE
     const void* w3p;    // T [cout][cexp], columns permuted
     const float* b3;    // [cout]
 };
@@ -98,10 +98,10 @@ int launch_block(int dt, const BlockParams& p, const void* x, void* out, int B, 
 struct StemDwParams {
     const void* wa;     // T [64][32]: row perm_pos(oc) holds output channel oc, columns = taps (c*9+ky*3+kx), 27..31 zero
     const float* b1;    // [64] natural order
-    const float* s1;
+    const float* s1;    // [64] PReLU slope MINUS ONE
     const void* w2;     // T [9][64] tap-major depthwise weights
     const float* b2;
-    const float* s2;
+    const float* s2;    // [64] PReLU slope MINUS ONE
 };
 int launch_stemdw(int dt, const StemDwParams& p, const float* x, void* out, int B, hipStream_t s);
 // T NHWC [n] -> f32 (debug taps)

@@ -23,7 +23,7 @@
 // expand epilogue through LDS and the depthwise stage into the project MFMA.  Everything indexed
 // by expanded channel on the depthwise/project side (bias, slope, 3x3 weights, project weight
 // columns) is stored pre-permuted on the host: natural channel 16g + 8a + 4h + i sits at
-// position 16g + 8h + 4a + i.
+// position 16g + 8h + 4a + i.  The two slope arrays hold (PReLU slope - 1): prelu(v) = v + (slope-1) min(v,0).
 #include "common.h"
 
 namespace fra {
@@ -139,7 +139,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     }
 
     // ---- output pixel of this lane per owned output tile ------------------------------------------
-    int out_base[MTOW];   // LDS slot of tap (0,0) for this lane's output pixel
+    int tap_off[MTOW][9]; // LDS byte offset of unit 0 of each of the 9 taps of this lane's output pixel
     int out_pix[MTOW];    // pixel index inside the image's output map, -1 = padding lane
 #pragma unroll
     for (int t = 0; t < MTOW; ++t) {
@@ -147,7 +147,13 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         const bool ok = (wave + NW * t < MTO) && (po < POUT);
         const int pc = ok ? po : 0;
         const int oy = pc / Wo, ox = pc - oy * Wo;
-        out_base[t] = (oy * S) * PITCH + ox * S;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int slot = (oy * S + ky) * PITCH + ox * S + kx;
+                tap_off[t][ky * 3 + kx] = slot * 128 + (eswz(slot) << 4);   // unit u lives at this ^ (u << 4)
+            }
         out_pix[t] = ok ? (y0 + oy) * Wo + ox : -1;
     }
 
@@ -205,7 +211,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 const float v = acc[4 * q + i];
-                                o[4 * a + i] = (T)(v > 0.0f ? v : v * sl[i]);
+                                o[4 * a + i] = (T)fmaf(fminf(v, 0.0f), sl[i], v);   // PReLU: sl = slope - 1
                             }
                         }
                         const int u = (2 * nt + s2) * 2 + h;          // 16-byte unit inside the 128-byte slot
@@ -243,8 +249,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const int slot = out_base[t] + ky * PITCH + kx;
-                        const V8 e = *reinterpret_cast<const V8*>(es + slot * 128 + ((u ^ eswz(slot)) << 4));
+                        const V8 e = *reinterpret_cast<const V8*>(es + (tap_off[t][ky * 3 + kx] ^ (u << 4)));
                         const V8 wk = *reinterpret_cast<const V8*>(w2base + (ky * 3 + kx) * CEXP * 2);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) d[j] = fmaf((float)e[j], (float)wk[j], d[j]);
@@ -252,8 +257,8 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
                 V8 bf;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    bf[j] = (T)(d[j] > 0.0f ? d[j] : d[j] * s2a[j]);
-                    bf[4 + j] = (T)(d[4 + j] > 0.0f ? d[4 + j] : d[4 + j] * s2b[j]);
+                    bf[j] = (T)fmaf(fminf(d[j], 0.0f), s2a[j], d[j]);               // PReLU: s2 = slope - 1
+                    bf[4 + j] = (T)fmaf(fminf(d[4 + j], 0.0f), s2b[j], d[4 + j]);
                 }
 #pragma unroll
                 for (int n3 = 0; n3 < NT3; ++n3) pacc[t][n3] = mfma32(a3[n3], bf, pacc[t][n3]);

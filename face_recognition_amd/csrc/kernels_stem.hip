@@ -117,7 +117,7 @@ void stemdw_kernel(const float* __restrict__ X, const T* __restrict__ WA, const 
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const float v = acc[4 * (2 * g + a) + i];
-                            o[4 * a + i] = (T)(v > 0.0f ? v : v * sl[i]);
+                            o[4 * a + i] = (T)fmaf(fminf(v, 0.0f), sl[i], v);   // PReLU: sl = slope - 1
                         }
                     }
                     const int u = 4 * m + 2 * g + h;       // channels [8u, 8u+8)
@@ -137,7 +137,14 @@ void stemdw_kernel(const float* __restrict__ X, const T* __restrict__ WA, const 
         const bool ok = po < POUT;
         const int pc = ok ? po : 0;
         const int oy = pc / W, ox = pc - oy * W;
-        const int base_slot = oy * PITCH + ox;
+        int tap_off[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int slot = (oy + ky) * PITCH + ox + kx;
+                tap_off[ky * 3 + kx] = slot * 128 + (eswz2(slot) << 4);
+            }
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const int u = 2 * s4 + h;
@@ -150,8 +157,7 @@ void stemdw_kernel(const float* __restrict__ X, const T* __restrict__ WA, const 
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int slot = base_slot + ky * PITCH + kx;
-                    const V8 e = *reinterpret_cast<const V8*>(es + slot * 128 + ((u ^ eswz2(slot)) << 4));
+                    const V8 e = *reinterpret_cast<const V8*>(es + (tap_off[ky * 3 + kx] ^ (u << 4)));
                     const V8 wk = *reinterpret_cast<const V8*>(lds + OFF_W2 + ((ky * 3 + kx) * 64 + 8 * u) * 2);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) d[j] = fmaf((float)e[j], (float)wk[j], d[j]);
@@ -161,8 +167,8 @@ void stemdw_kernel(const float* __restrict__ X, const T* __restrict__ WA, const 
             V8 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                o[j] = (T)(d[j] > 0.0f ? d[j] : d[j] * s2a[j]);
-                o[4 + j] = (T)(d[4 + j] > 0.0f ? d[4 + j] : d[4 + j] * s2b[j]);
+                o[j] = (T)fmaf(fminf(d[j], 0.0f), s2a[j], d[j]);                  // PReLU: s2 = slope - 1
+                o[4 + j] = (T)fmaf(fminf(d[4 + j], 0.0f), s2b[j], d[4 + j]);
             }
             if (ok) *reinterpret_cast<V8*>(Oimg + ((size_t)(y0 + oy) * W + ox) * 64 + 8 * u) = o;
         }

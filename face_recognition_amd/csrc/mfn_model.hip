@@ -29,7 +29,8 @@ struct Op {
     const float* bias = nullptr;
     const float* slope = nullptr;
     size_t w_off = 0, bias_off = 0, slope_off = 0;  // arena offsets
-    double flops = 0, bytes = 0;                    // per image
+    double flops = 0, bytes = 0;                    // per image (activations in + out)
+    double wbytes = 0;                              // parameters, read once per launch
     // OP_BLOCK only: expanded width, shortcut flag, arena offsets of the eight parameter arrays
     int cexp = 0;
     bool residual = false;
@@ -75,29 +76,34 @@ static void build_ops(mfn_handle* h, bool fused) {
         switch (k) {
             case OP_STEM:
                 o.flops = 2.0 * px_out * cout * 27;
-                o.bytes = px_in * 3 * 4 + px_out * cout * es + 27 * 64 * 4;
+                o.bytes = px_in * 3 * 4 + px_out * cout * es;
+                o.wbytes = 27 * 64 * 4;
                 break;
             case OP_DW:
                 o.flops = 2.0 * px_out * cout * 9;
-                o.bytes = (px_in * cin + px_out * cout) * es + 9.0 * cout * es;
+                o.bytes = (px_in * cin + px_out * cout) * es;
+                o.wbytes = 9.0 * cout * es;
                 break;
             case OP_PW:
                 o.flops = 2.0 * px_out * cin * cout;
-                o.bytes = (px_in * cin + px_out * cout + (resid != NO_RESID ? px_out * cout : 0)) * es +
-                          (double)cin * cout * es;
+                o.bytes = (px_in * cin + px_out * cout + (resid != NO_RESID ? px_out * cout : 0)) * es;
+                o.wbytes = (double)cin * cout * es;
                 break;
             case OP_GDCONV:
                 o.flops = 2.0 * 49 * cout;
-                o.bytes = (49.0 * cin + cout) * es + 49.0 * cout * es;
+                o.bytes = (49.0 * cin + cout) * es;
+                o.wbytes = 49.0 * cout * es;
                 break;
             case OP_LINEAR:
                 o.flops = 2.0 * cin * cout;
-                o.bytes = cin * es + cout * 4.0 + (double)cin * cout * es;
+                o.bytes = cin * es + cout * 4.0;
+                o.wbytes = (double)cin * cout * es;
                 break;
             case OP_BLOCK: break;  // filled in by the caller
             case OP_STEMDW:
                 o.flops = 2.0 * px_out * 64 * 27 + 2.0 * px_out * 64 * 9;
-                o.bytes = px_in * 3 * 4 + px_out * 64 * es + 64 * 32 * es + 9 * 64 * es;
+                o.bytes = px_in * 3 * 4 + px_out * 64 * es;
+                o.wbytes = 64 * 32 * es + 9 * 64 * es;
                 break;
         }
         ops.push_back(o);
@@ -120,7 +126,8 @@ static void build_ops(mfn_handle* h, bool fused) {
             o.residual = res;
             const double pin = (double)hin * hin, pout = (double)hout * hout;
             o.flops = 2.0 * (pin * cin * cexp + pout * cexp * 9 + pout * cexp * cout);
-            o.bytes = (pin * cin + pout * cout) * es + ((double)cin * cexp + 9.0 * cexp + (double)cexp * cout) * es;
+            o.bytes = (pin * cin + pout * cout) * es;    // the shortcut re-reads the input tile: no extra traffic
+            o.wbytes = ((double)cin * cexp + 9.0 * cexp + (double)cexp * cout) * es;
             cur = other;
             return;
         }
@@ -267,7 +274,7 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
                 for (int t = 0; t < 32; ++t)
                     wa[perm_pos(oc) * 32 + t] = to16(dt, t < 27 ? (float)(w[oc * 27 + t] * scale[oc]) : 0.0f);
                 b1[oc] = (float)shift[oc];
-                s1[oc] = a[oc];
+                s1[oc] = a[oc] - 1.0f;
             }
             if ((rc = fetch(m, "conv2_dw.conv.weight", 64 * 9, &w))) return rc;
             if ((rc = bn_fold(m, "conv2_dw.bn", 64, scale, shift))) return rc;
@@ -275,7 +282,7 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
             for (int c = 0; c < 64; ++c) {
                 for (int t = 0; t < 9; ++t) w2[t * 64 + c] = to16(dt, (float)(w[c * 9 + t] * scale[c]));
                 b2[c] = (float)shift[c];
-                s2[c] = a[c];
+                s2[c] = a[c] - 1.0f;
             }
             continue;
         }
@@ -297,7 +304,7 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
             for (int e = 0; e < CE; ++e) {
                 for (int k = 0; k < CI; ++k) w1[(size_t)e * CI + k] = to16(dt, (float)(w[(size_t)e * CI + k] * scale[e]));
                 b1p[perm_pos(e)] = (float)shift[e];
-                s1p[perm_pos(e)] = a[e];
+                s1p[perm_pos(e)] = a[e] - 1.0f;   // kernels compute v + (slope-1) min(v,0)
             }
             if ((rc = fetch(m, o.name + ".conv_dw.conv.weight", (int64_t)CE * 9, &w))) return rc;
             if ((rc = bn_fold(m, o.name + ".conv_dw.bn", CE, scale, shift))) return rc;
@@ -305,7 +312,7 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
             for (int e = 0; e < CE; ++e) {
                 for (int t = 0; t < 9; ++t) w2p[(size_t)t * CE + perm_pos(e)] = to16(dt, (float)(w[(size_t)e * 9 + t] * scale[e]));
                 b2p[perm_pos(e)] = (float)shift[e];
-                s2p[perm_pos(e)] = a[e];
+                s2p[perm_pos(e)] = a[e] - 1.0f;
             }
             if ((rc = fetch(m, o.name + ".project.conv.weight", (int64_t)C * CE, &w))) return rc;
             if ((rc = bn_fold(m, o.name + ".project.bn", C, scale, shift))) return rc;
@@ -544,7 +551,8 @@ int mfn_forward_timed(mfn_handle* h, const float* x, int B, float* out, void* ws
 
 int mfn_op_count(const mfn_handle* h) { return h ? (int)h->ops().size() : -1; }
 
-int mfn_op_info(const mfn_handle* h, int op, char* name, int name_cap, int* kind, double* flops, double* bytes) {
+int mfn_op_info(const mfn_handle* h, int op, char* name, int name_cap, int* kind, double* flops, double* bytes,
+                double* weight_bytes) {
     FRA_REQUIRE(h && op >= 0 && op < (int)h->ops().size(), FRA_ERR_ARG, "mfn_op_info: bad argument");
     const Op& o = h->ops()[op];
     if (name && name_cap > 0) {
@@ -554,6 +562,7 @@ int mfn_op_info(const mfn_handle* h, int op, char* name, int name_cap, int* kind
     if (kind) *kind = (int)o.kind;
     if (flops) *flops = o.flops;
     if (bytes) *bytes = o.bytes;
+    if (weight_bytes) *weight_bytes = o.wbytes;
     return FRA_OK;
 }
 

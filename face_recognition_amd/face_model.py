@@ -234,7 +234,7 @@ class MobileFaceNet(nn.Module):
         return out, np.array(list(ms), dtype=np.float64), self.op_table()
 
     def op_table(self):
-        """[(name, kind, flops_per_image, bytes_per_image)] for every kernel of the forward."""
+        """[(name, kind, flops_per_image, activation_bytes_per_image, weight_bytes)] for every kernel of the forward."""
         lib = _lib.load()
         if self._handle is None:
             raise RuntimeError("op_table: run a forward first")
@@ -242,10 +242,10 @@ class MobileFaceNet(nn.Module):
         rows = []
         for i in range(lib.mfn_op_count(self._handle)):
             name = C.create_string_buffer(96)
-            kind, fl, by = C.c_int(), C.c_double(), C.c_double()
-            _lib.check(lib.mfn_op_info(self._handle, i, name, 96, C.byref(kind), C.byref(fl), C.byref(by)),
+            kind, fl, by, wb = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+            _lib.check(lib.mfn_op_info(self._handle, i, name, 96, C.byref(kind), C.byref(fl), C.byref(by), C.byref(wb)),
                        "mfn_op_info")
-            rows.append((name.value.decode(), kinds[kind.value], fl.value, by.value))
+            rows.append((name.value.decode(), kinds[kind.value], fl.value, by.value, wb.value))
         return rows
 
     def debug_prefix(self, x: torch.Tensor, n_ops: int) -> torch.Tensor:

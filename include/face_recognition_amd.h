@@ -81,9 +81,10 @@ int mfn_forward_timed(mfn_handle* h, const float* x_nchw, int B, float* out, voi
                       size_t workspace_bytes, fra_stream stream, float* op_ms, int n_ops);
 int mfn_op_count(const mfn_handle* h);
 /* kind: 0 stem, 1 depthwise 3x3, 2 pointwise, 3 gdconv 7x7, 4 linear+l2norm, 5 fused block, 6 fused stem + first depthwise.  flops / bytes are the
- * algorithmic work and HBM traffic (inputs + outputs + weights) of the op for ONE image. */
+ * algorithmic work and HBM traffic (activations read + written) of the op for ONE image; weight_bytes
+ * are its parameters, read once per launch whatever the batch. */
 int mfn_op_info(const mfn_handle* h, int op, char* name, int name_cap, int* kind, double* flops_per_image,
-                double* bytes_per_image);
+                double* bytes_per_image, double* weight_bytes);
 
 /* Debug tap: run the first n_ops ops on x and write that op's output activation, converted to
  * f32, NHWC, to out_nhwc_f32 (dev).  *numel_per_image receives its per-image element count. */
@@ -106,7 +107,8 @@ int mfn_op_pw(int dtype, const void* in, const void* wNxK, const float* bias, co
               const void* resid_or_null, void* out, int64_t M, int K, int N, fra_stream stream);
 /* Fused inverted-residual block (face_model.py:55-65).  Arrays indexed by expanded channel on the
  * depthwise / project side (b1p, s1p, w2p [9][cexp], b2p, s2p, columns of w3p [cout][cexp]) are in
- * the kernel's permuted channel order: natural channel 16g+8a+4h+i is stored at 16g+8h+4a+i. */
+ * the kernel's permuted channel order: natural channel 16g+8a+4h+i is stored at 16g+8h+4a+i.
+ * s1p / s2p hold (PReLU slope - 1): the kernel evaluates v + (slope-1)*min(v,0). */
 int mfn_op_block(int dtype, int cin, int cexp, int cout, int h, int stride, int residual, const void* x,
                  const void* w1, const float* b1p, const float* s1p, const void* w2p, const float* b2p,
                  const float* s2p, const void* w3p, const float* b3, void* out, int B, fra_stream stream);

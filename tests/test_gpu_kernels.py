@@ -135,9 +135,9 @@ def test_fused_block(device, dt, cin, cexp, cout, H, stride, res, B):
     inv[perm] = torch.arange(cexp)                # inv[pos] = natural channel stored at pos
     dev = lambda t: t.contiguous().to(device)    # noqa: E731
     xd = dev(x.permute(0, 2, 3, 1).to(tdt))
-    w1d, b1d, s1d = dev(w1.to(tdt)), dev(b1[inv]), dev(s1[inv])
+    w1d, b1d, s1d = dev(w1.to(tdt)), dev(b1[inv]), dev(s1[inv] - 1.0)      # slopes travel as slope - 1
     w2d = dev(w2.reshape(cexp, 9).t()[:, inv].to(tdt))
-    b2d, s2d = dev(b2[inv]), dev(s2[inv])
+    b2d, s2d = dev(b2[inv]), dev(s2[inv] - 1.0)
     w3d, b3d = dev(w3[:, inv].to(tdt)), dev(b3)
     Ho = H // stride
     out = torch.full((B, Ho, Ho, cout), float("nan"), dtype=tdt, device=device)

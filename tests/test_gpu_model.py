@@ -40,7 +40,7 @@ def test_layer_by_layer_against_oracle(hip_model, device, state_dict_np):
     hip_model(x)  # builds the handle
     table = hip_model.op_table()
     worst = 0.0
-    for i, (name, kind, _, _) in enumerate(table[:-1]):
+    for i, (name, kind, *_rest) in enumerate(table[:-1]):
         # oracle taps exist at block granularity: stem, conv2_dw, block outputs (= project ops), conv_6_sep, conv_6_dw
         key = name[:-len(".project")] if name.endswith(".project") else name
         if key not in taps or name.endswith(".conv") or name.endswith(".conv_dw"):
