@@ -179,20 +179,34 @@ def run_search(args, rank, world, dev, dist_mod):
 
 
 def latency(net, dev):
-    out = {}
-    for B in (1, 8):
-        x = torch.rand((B, 3, 112, 112), device=dev) * 2 - 1
-        for _ in range(20):
-            net(x)
+    """Small-batch latency (BASELINE configs[2]): host wall time per call incl. the final sync, eager launches
+    vs one hipGraph replay of forward + match against a 1000-row facebank."""
+    from face_recognition_amd.facebank import match_facebank
+    from face_recognition_amd.graphed import GraphedRecognizer
+    bank = torch.from_numpy(synthetic.unit_rows(1000, 512, seed=2)).to(dev)
+    rec = GraphedRecognizer(net, bank, tta=False, threshold=60)
+    rec_tta = GraphedRecognizer(net, bank, tta=True, threshold=60)
+
+    def timeit(fn, x, reps=300):
+        for _ in range(30):
+            fn(x)
         torch.cuda.synchronize()
         ts = []
-        for _ in range(200):
+        for _ in range(reps):
             t0 = time.perf_counter()
-            net(x)
+            fn(x)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
         ts = np.sort(np.array(ts)) * 1e6
-        out[f"forward_b{B}"] = {"p50": round(float(ts[len(ts) // 2]), 1), "p99": round(float(ts[int(len(ts) * 0.99)]), 1)}
+        return {"p50": round(float(ts[len(ts) // 2]), 1), "p99": round(float(ts[int(len(ts) * 0.99)]), 1)}
+
+    out = {}
+    for B in (1, 2, 4, 8):
+        x = torch.rand((B, 3, 112, 112), device=dev) * 2 - 1
+        out[f"b{B}"] = {"eager_forward": timeit(net, x, 100),
+                        "eager_forward_match": timeit(lambda t: match_facebank(net(t), bank, 60), x, 100),
+                        "graph_forward_match": timeit(rec, x),
+                        "graph_tta_forward_match": timeit(rec_tta, x)}
     return out
 
 

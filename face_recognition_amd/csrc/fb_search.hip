@@ -22,9 +22,12 @@ struct fb_handle {
     int64_t index_base = 0;
     void* rows = nullptr;      // f32 [N][D] or 16-bit [Npad][D]
     float* negh = nullptr;     // -|g|^2/2 per row (16-bit modes), -inf in padding rows
-    // scratch, grown on demand
+    // scratch, grown on demand.  A block that has been handed to kernels is never freed before
+    // fb_destroy: a captured hipGraph may still hold its address.
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
+    void* retired[32] = {nullptr};
+    int n_retired = 0;
 };
 
 namespace fra {
@@ -324,11 +327,19 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int ensure_scratch(fb_handle* h, size_t bytes) {
     if (h->scratch_bytes >= bytes) return FRA_OK;
-    if (h->scratch) FRA_HIP(hipFree(h->scratch));
-    h->scratch = nullptr;
-    h->scratch_bytes = 0;
-    FRA_HIP(hipMalloc(&h->scratch, bytes));
-    h->scratch_bytes = bytes;
+    size_t want = bytes > 2 * h->scratch_bytes ? bytes : 2 * h->scratch_bytes;   // geometric growth bounds the retired list
+    void* fresh = nullptr;
+    FRA_HIP(hipMalloc(&fresh, want));
+    if (h->scratch) {
+        if (h->n_retired < 32) {
+            h->retired[h->n_retired++] = h->scratch;
+        } else {                       // cannot happen with doubling (2^32 growth); drain and free rather than leak
+            (void)hipDeviceSynchronize();
+            (void)hipFree(h->scratch);
+        }
+    }
+    h->scratch = fresh;
+    h->scratch_bytes = want;
     return FRA_OK;
 }
 
@@ -500,6 +511,16 @@ int fb_fill(fb_handle* h, int64_t row0, const float* rows, int rows_is_device, i
 
 int64_t fb_rows(const fb_handle* h) { return h ? h->N : -1; }
 
+int fb_reserve(fb_handle* h, int max_queries) {
+    FRA_REQUIRE(h && max_queries > 0, FRA_ERR_ARG, "fb_reserve: bad argument");
+    FRA_HIP(hipSetDevice(h->device));
+    if (h->store == FRA_F32) return ensure_scratch(h, align_up((size_t)max_queries * h->N * 4, 256));
+    const int QT = (max_queries + BQ - 1) / BQ, Qpad = QT * BQ;
+    const size_t P = 128, KS = 8;   // upper bounds of the partial-list layout in search_packed
+    return ensure_scratch(h, align_up((size_t)Qpad * h->D * 2, 256) + align_up((size_t)Qpad * 4, 256) +
+                                 2 * align_up(P * Qpad * KS * 4, 256));
+}
+
 int fb_search_l2_topk(fb_handle* h, const float* queries, int Q, int k, float* dist_out, int32_t* idx_out,
                       fra_stream stream) {
     FRA_REQUIRE(h && queries && dist_out && idx_out, FRA_ERR_ARG, "fb_search: null pointer");
@@ -538,6 +559,7 @@ int fb_destroy(fb_handle* h) {
     if (h->rows) (void)hipFree(h->rows);
     if (h->negh) (void)hipFree(h->negh);
     if (h->scratch) (void)hipFree(h->scratch);
+    for (int i = 0; i < h->n_retired; ++i) (void)hipFree(h->retired[i]);
     delete h;
     return FRA_OK;
 }

@@ -204,12 +204,23 @@ class MobileFaceNet(nn.Module):
             raise RuntimeError("empty batch")
         return x.detach().to(torch.float32).contiguous()
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def workspace_bytes(self, batch: int, device=None) -> int:
+        """Bytes of scratch a forward of ``batch`` crops needs (for callers that bring their own workspace)."""
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        with torch.cuda.device(dev):
+            lib = self._ensure_handle(dev)
+            need = C.c_size_t()
+            _lib.check(lib.mfn_workspace_bytes(self._handle, batch, C.byref(need)), "mfn_workspace_bytes")
+        return int(need.value)
+
+    def forward(self, x: torch.Tensor, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``workspace``: optional caller-owned uint8 device tensor of at least ``workspace_bytes(B)``
+        bytes (256-byte aligned); by default the module keeps and grows its own."""
         x = self._check_input(x)
         dev = x.device
         with torch.cuda.device(dev):
             lib = self._ensure_handle(dev)
-            ws = self._ensure_workspace(lib, x.shape[0], dev)
+            ws = workspace if workspace is not None else self._ensure_workspace(lib, x.shape[0], dev)
             out = torch.empty((x.shape[0], self.embedding_size), dtype=torch.float32, device=dev)
             _lib.check(lib.mfn_forward(self._handle, x.data_ptr(), x.shape[0], out.data_ptr(), ws.data_ptr(),
                                        ws.numel(), _lib.current_stream_ptr(dev)), "mfn_forward")

@@ -88,6 +88,11 @@ class Gallery:
             _lib.check(_lib.load().fb_fill(self._h, int(row0), rows.data_ptr(), 1 if rows.is_cuda else 0,
                                            int(rows.shape[0])), "fb_fill")
 
+    def reserve(self, max_queries: int) -> None:
+        """Pre-size internal scratch for searches of up to ``max_queries`` queries (needed before graph capture)."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().fb_reserve(self._h, int(max_queries)), "fb_reserve")
+
     def search(self, queries: torch.Tensor, k: int = 5) -> Tuple[torch.Tensor, torch.Tensor]:
         """(dist f32 [Q,k] ascending, idx int32 [Q,k]) on the device; ties -> lowest index; empty slots (inf, -1)."""
         if queries.dim() != 2 or queries.shape[1] != self.d:

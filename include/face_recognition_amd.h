@@ -131,6 +131,10 @@ int fb_create(fb_handle** out, int device, const float* gallery, int gallery_is_
  * large shard be produced piecewise on the device.  Synchronous. */
 int fb_fill(fb_handle* h, int64_t row0, const float* rows, int rows_is_device, int64_t n);
 int64_t fb_rows(const fb_handle* h);
+/* Pre-size the handle's internal scratch for searches of up to max_queries queries, so that no
+ * search of that size allocates (e.g. before capturing searches into a hipGraph).  Scratch only
+ * grows, and blocks already used are kept until fb_destroy, so captured graphs stay valid. */
+int fb_reserve(fb_handle* h, int max_queries);
 
 /* dist_out[q,j], idx_out[q,j] (dev, [Q,k]) = the k smallest squared L2 distances
  * sum_d (q[d]-g[n,d])^2 and their (global) indices, ascending; equal distances -> lowest index.
