@@ -279,8 +279,16 @@ def main():
         groups, total_ms = per_kernel_profile(net, x, 3, args.dtype)
         dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
         gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        traffic = None   # HBM bytes per launch from rocprofv3 PMC passes (profiles/, separate runs of this command)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
+        except OSError:
+            pass
         result["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dom_name,
+                              "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": dom_name,
+                              "mfma_tflops": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 1),
+                              "mfma_frac": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                               "launches_per_step": dom["launches"],
                               "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                               "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),

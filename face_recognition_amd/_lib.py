@@ -32,6 +32,8 @@ SIGNATURES = {
     "mfn_set_batch_chunk": (_I, [_P, _I]),
     "mfn_set_fused": (_I, [_P, _I]),
     "mfn_forward": (_I, [_P, _P, _I, _P, _P, C.c_size_t, _P]),
+    "mfn_forward_ex": (_I, [_P, _P, _I, _I, _I, _P, _P, C.c_size_t, _P]),
+    "mfn_workspace_bytes_ex": (_I, [_P, _I, _I, C.POINTER(C.c_size_t)]),
     "mfn_forward_timed": (_I, [_P, _P, _I, _P, _P, C.c_size_t, _P, C.POINTER(C.c_float), _I]),
     "mfn_op_count": (_I, [_P]),
     "mfn_op_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_I), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),

@@ -94,7 +94,8 @@ struct BlockParams {
 // position of natural expanded channel c = 16g + 8a + 4h + i in the permuted order: 16g + 8h + 4a + i
 inline int perm_pos(int c) { return (c & ~15) | ((c & 4) << 1) | ((c & 8) >> 1) | (c & 3); }
 int launch_block(int dt, const BlockParams& p, const void* x, void* out, int B, hipStream_t s);
-// fused head: stem conv (3->64, 3x3 s2, PReLU) + depthwise 3x3 (64 ch, PReLU); x f32 NCHW -> out T NHWC [B,56,56,64]
+// fused head: stem conv (3->64, 3x3 s2, PReLU) + depthwise 3x3 (64 ch, PReLU) -> out T NHWC [B,56,56,64].
+// x: n_src crops, f32 NCHW in [-1,1] or (x_is_u8) uint8 HWC; images n_src..B-1 are mirrored copies of images 0..B-n_src-1
 struct StemDwParams {
     const void* wa;     // T [64][32]: row perm_pos(oc) holds output channel oc, columns = taps (c*9+ky*3+kx), 27..31 zero
     const float* b1;    // [64] natural order
@@ -103,7 +104,7 @@ struct StemDwParams {
     const float* b2;
     const float* s2;    // [64] PReLU slope MINUS ONE
 };
-int launch_stemdw(int dt, const StemDwParams& p, const float* x, void* out, int B, hipStream_t s);
+int launch_stemdw(int dt, const StemDwParams& p, const void* x, int x_is_u8, int n_src, void* out, int B, hipStream_t s);
 // T NHWC [n] -> f32 (debug taps)
 int launch_to_f32(int dt, const void* in, float* out, int64_t n, hipStream_t s);
 

@@ -39,7 +39,7 @@ template <int CH> __device__ __forceinline__ int bswz(int row) {
 // consecutive slots sees 8 even and 8 odd slots, each set with 8 distinct XOR keys: conflict free.
 __device__ __forceinline__ int eswz(int slot) { return (slot >> 1) & 7; }
 
-template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW>
+template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW, bool DB>
 __global__ __launch_bounds__(NW * 64, MINW)
 void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float* __restrict__ b1p,
                   const float* __restrict__ s1p, const T* __restrict__ W2p, const float* __restrict__ b2p,
@@ -59,10 +59,12 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     constexpr int KS1 = CIN / 16, NT3 = COUT / 32, NCH = CEXP / 64;
     constexpr int PITCH = W + 2;                           // pixel slots per LDS row (zero border each side)
     constexpr int CH1 = CIN / 8;                           // 16-byte chunks per row of the W1 slice
-    // LDS map
+    // LDS map.  DB: two activation images and two copies of each weight slice, so that the expand of
+    // slice c+1 and the depthwise/project of slice c run between the same pair of barriers.
+    constexpr int NB = DB ? 2 : 1;
     constexpr int ES_BYTES = RIN * PITCH * 128;
     constexpr int W1_BYTES = 64 * CIN * 2, W3_BYTES = COUT * 64 * 2;
-    constexpr int OFF_W1 = ES_BYTES, OFF_W3 = OFF_W1 + W1_BYTES, OFF_PAR = OFF_W3 + W3_BYTES;
+    constexpr int OFF_W1 = NB * ES_BYTES, OFF_W3 = OFF_W1 + NB * W1_BYTES, OFF_PAR = OFF_W3 + NB * W3_BYTES;
     constexpr int OFF_B1 = OFF_PAR, OFF_S1 = OFF_B1 + CEXP * 4, OFF_B2 = OFF_S1 + CEXP * 4, OFF_S2 = OFF_B2 + CEXP * 4,
                   OFF_W2 = OFF_S2 + CEXP * 4;
     constexpr int LDS_BYTES = OFF_W2 + 9 * CEXP * 2;
@@ -72,7 +74,6 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     static_assert(!RESID || (S == 1 && CIN == COUT), "shortcut needs matching shapes");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* const es = lds;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -82,36 +83,43 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 
     // ---- weight-slice staging: global -> registers (issued early) -> swizzled LDS (behind a barrier) ----
     V8 wreg1[W1_PT], wreg3[W3_PT];
-    auto fetch_slice = [&](int c) {
+    auto fetch_w1 = [&](int c) {
 #pragma unroll
         for (int i = 0; i < W1_PT; ++i) {
             const int v = tid + i * NT;
             if (v < W1_V) wreg1[i] = *reinterpret_cast<const V8*>(W1 + (size_t)c * 64 * CIN + (size_t)v * 8);
         }
+    };
+    auto fetch_w3 = [&](int c) {
 #pragma unroll
         for (int i = 0; i < W3_PT; ++i) {
             const int v = tid + i * NT;
             if (v < W3_V) wreg3[i] = *reinterpret_cast<const V8*>(W3p + (size_t)(v >> 3) * CEXP + c * 64 + (v & 7) * 8);
         }
     };
-    auto store_slice = [&]() {
+    auto store_w1 = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < W1_PT; ++i) {
             const int v = tid + i * NT;
             const int row = v / CH1, ch = v - row * CH1;
-            if (v < W1_V) *reinterpret_cast<V8*>(lds + OFF_W1 + ((row * CH1 + (ch ^ bswz<CH1>(row))) << 4)) = wreg1[i];
+            if (v < W1_V)
+                *reinterpret_cast<V8*>(lds + OFF_W1 + buf * W1_BYTES + ((row * CH1 + (ch ^ bswz<CH1>(row))) << 4)) = wreg1[i];
         }
+    };
+    auto store_w3 = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < W3_PT; ++i) {
             const int v = tid + i * NT;
             const int row = v >> 3, ch = v & 7;
-            if (v < W3_V) *reinterpret_cast<V8*>(lds + OFF_W3 + ((row * 8 + (ch ^ bswz<8>(row))) << 4)) = wreg3[i];
+            if (v < W3_V)
+                *reinterpret_cast<V8*>(lds + OFF_W3 + buf * W3_BYTES + ((row * 8 + (ch ^ bswz<8>(row))) << 4)) = wreg3[i];
         }
     };
-    fetch_slice(0);
+    fetch_w1(0);
+    fetch_w3(0);
 
-    // zero the activation image once: borders and out-of-image rows are never written afterwards
-    for (int i = tid; i < ES_BYTES / 16; i += NT) reinterpret_cast<f32x4*>(es)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // zero the activation image(s) once: borders and out-of-image rows are never written afterwards
+    for (int i = tid; i < NB * ES_BYTES / 16; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // per-channel parameters of all slices
     for (int i = tid; i < CEXP / 4; i += NT) {
         reinterpret_cast<f32x4*>(lds + OFF_B1)[i] = reinterpret_cast<const f32x4*>(b1p)[i];
@@ -169,19 +177,18 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 #pragma unroll
                 for (int i = 0; i < 4; ++i) pacc[t][n3][4 * q + i] = b[i];
         }
-    store_slice();
-    __syncthreads();
 
-#pragma unroll 1
-    for (int c = 0; c < NCH; ++c) {
-        // ================= expand: E[64 ch][pixels] = PReLU(W1 . X + b1) -> LDS =================
+    // ================= expand of slice c: E[64 ch][pixels] = PReLU(W1 . X + b1) -> LDS image eb =================
+    auto expand = [&](int c, int eb, int wb) {
+        char* const es = lds + eb * ES_BYTES;
+        const char* const w1s = lds + OFF_W1 + wb * W1_BYTES;
 #pragma unroll 1
         for (int nt = 0; nt < 2; ++nt) {
             V8 w1[KS1];
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
                 const int row = nt * 32 + r, ch = 2 * ks + h;
-                w1[ks] = *reinterpret_cast<const V8*>(lds + OFF_W1 + ((row * CH1 + (ch ^ bswz<CH1>(row))) << 4));
+                w1[ks] = *reinterpret_cast<const V8*>(w1s + ((row * CH1 + (ch ^ bswz<CH1>(row))) << 4));
             }
             // bias / slope of this lane's 16 channels: groups g16 = 4c + 2nt + (q>>1), position 16 g16 + 8h + 4(q&1) + i
             f32x4 bq[4];
@@ -220,11 +227,13 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
                 }
             }
         }
-        if (c + 1 < NCH) fetch_slice(c + 1);   // in flight during the depthwise / project phase
-        __syncthreads();
+    };
 
-        // ================= depthwise 3x3 from LDS -> project MFMA =================================
-#pragma unroll 1
+    // ================= depthwise 3x3 of slice c from LDS image eb -> project MFMA =================================
+    auto dwproject = [&](int c, int eb, int wb) {
+        const char* const es = lds + eb * ES_BYTES;
+        const char* const w3s = lds + OFF_W3 + wb * W3_BYTES;
+#pragma unroll 2
         for (int s4 = 0; s4 < 4; ++s4) {                  // 16-channel k-step of the slice
             const int pos = c * 64 + 16 * s4 + 8 * h;     // permuted position of this half's 8 channels
             const int u = 2 * s4 + h;
@@ -237,7 +246,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 #pragma unroll
             for (int n3 = 0; n3 < NT3; ++n3) {
                 const int row = 32 * n3 + r, ch = 2 * s4 + h;
-                a3[n3] = *reinterpret_cast<const V8*>(lds + OFF_W3 + ((row * 8 + (ch ^ bswz<8>(row))) << 4));
+                a3[n3] = *reinterpret_cast<const V8*>(w3s + ((row * 8 + (ch ^ bswz<8>(row))) << 4));
             }
 #pragma unroll
             for (int t = 0; t < MTOW; ++t) {
@@ -264,9 +273,45 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
                 for (int n3 = 0; n3 < NT3; ++n3) pacc[t][n3] = mfma32(a3[n3], bf, pacc[t][n3]);
             }
         }
-        __syncthreads();   // every wave is done with this slice's LDS image and weights
-        if (c + 1 < NCH) {
-            store_slice();
+    };
+
+    if (!DB) {
+        // one image, one copy of the weight slices: expand | barrier | depthwise+project | barrier | restage | barrier
+        store_w1(0);
+        store_w3(0);
+        __syncthreads();
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            expand(c, 0, 0);
+            if (c + 1 < NCH) { fetch_w1(c + 1); fetch_w3(c + 1); }   // in flight during the depthwise / project phase
+            __syncthreads();
+            dwproject(c, 0, 0);
+            __syncthreads();   // every wave is done with this slice's LDS image and weights
+            if (c + 1 < NCH) {
+                store_w1(0);
+                store_w3(0);
+                __syncthreads();
+            }
+        }
+    } else {
+        // software pipeline over slices: between two barriers a wave expands slice c+1 into one image and runs
+        // depthwise+project of slice c from the other.  W1 of slice c sits in buffer c&1, W3 likewise.
+        store_w1(0);
+        store_w3(0);
+        if (NCH > 1) fetch_w1(1);
+        __syncthreads();
+        expand(0, 0, 0);
+        if (NCH > 1) store_w1(1);
+        __syncthreads();
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 2 < NCH) fetch_w1(c + 2);
+            if (c + 1 < NCH) fetch_w3(c + 1);
+            if (c + 1 < NCH) expand(c + 1, (c + 1) & 1, (c + 1) & 1);
+            dwproject(c, c & 1, c & 1);
+            // W1 buffer c&1 held slice c (last read before the previous barrier); W3 buffer (c+1)&1 held slice c-1
+            if (c + 2 < NCH) store_w1(c & 1);
+            if (c + 1 < NCH) store_w3((c + 1) & 1);
             __syncthreads();
         }
     }
@@ -298,18 +343,18 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int CEXP, int COUT, int H, int S, int TR>
+template <int CIN, int CEXP, int COUT, int H, int S, int TR, bool DB>
 constexpr int block_lds_bytes() {
     constexpr int RIN = (S == 1) ? TR + 2 : 2 * TR + 1;
-    return RIN * (H + 2) * 128 + 64 * CIN * 2 + COUT * 64 * 2 + 4 * CEXP * 4 + 9 * CEXP * 2;
+    return (DB ? 2 : 1) * (RIN * (H + 2) * 128 + 64 * CIN * 2 + COUT * 64 * 2) + 4 * CEXP * 4 + 9 * CEXP * 2;
 }
 
-template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW>
+template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW, bool DB>
 static int launch_block_cfg(const BlockParams& p, const void* x, void* out, int B, hipStream_t s) {
     FRA_REQUIRE(p.cout == COUT, FRA_ERR_ARG, "block: cout %d, fused kernel has %d", p.cout, COUT);
     const dim3 grid((H / S) / TR, B), block(NW * 64);
-    constexpr int lds = block_lds_bytes<CIN, CEXP, COUT, H, S, TR>();
-    auto kern = block_kernel<T, CIN, CEXP, COUT, H, S, TR, RESID, NW, MINW>;
+    constexpr int lds = block_lds_bytes<CIN, CEXP, COUT, H, S, TR, DB>();
+    auto kern = block_kernel<T, CIN, CEXP, COUT, H, S, TR, RESID, NW, MINW, DB>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         FRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -326,17 +371,17 @@ static int launch_block_t(const BlockParams& p, const void* x, void* out, int B,
     const int key = p.cin * 1000000 + p.cexp * 1000 + p.h * 10 + p.stride;
     switch (key) {
         case 64 * 1000000 + 128 * 1000 + 56 * 10 + 2:   // conv_23
-            return launch_block_cfg<T, 64, 128, 64, 56, 2, 4, false, 8, 2>(p, x, out, B, s);
+            return launch_block_cfg<T, 64, 128, 64, 56, 2, 4, false, 8, 2, false>(p, x, out, B, s);
         case 64 * 1000000 + 128 * 1000 + 28 * 10 + 1:   // conv_3.*
-            return launch_block_cfg<T, 64, 128, 64, 28, 1, 7, true, 8, 4>(p, x, out, B, s);
+            return launch_block_cfg<T, 64, 128, 64, 28, 1, 7, true, 8, 4, false>(p, x, out, B, s);
         case 64 * 1000000 + 256 * 1000 + 28 * 10 + 2:   // conv_34
-            return launch_block_cfg<T, 64, 256, 128, 28, 2, 7, false, 8, 2>(p, x, out, B, s);
+            return launch_block_cfg<T, 64, 256, 128, 28, 2, 7, false, 8, 2, false>(p, x, out, B, s);
         case 128 * 1000000 + 256 * 1000 + 14 * 10 + 1:  // conv_4.*
-            return launch_block_cfg<T, 128, 256, 128, 14, 1, 14, true, 8, 2>(p, x, out, B, s);
+            return launch_block_cfg<T, 128, 256, 128, 14, 1, 14, true, 8, 2, true>(p, x, out, B, s);
         case 128 * 1000000 + 512 * 1000 + 14 * 10 + 2:  // conv_45
-            return launch_block_cfg<T, 128, 512, 128, 14, 2, 7, false, 8, 2>(p, x, out, B, s);
+            return launch_block_cfg<T, 128, 512, 128, 14, 2, 7, false, 8, 2, true>(p, x, out, B, s);
         case 128 * 1000000 + 256 * 1000 + 7 * 10 + 1:   // conv_5.*
-            return launch_block_cfg<T, 128, 256, 128, 7, 1, 7, true, 8, 2>(p, x, out, B, s);
+            return launch_block_cfg<T, 128, 256, 128, 7, 1, 7, true, 8, 2, true>(p, x, out, B, s);
         default: break;
     }
     FRA_REQUIRE(false, FRA_ERR_ARG, "block: no fused kernel for cin=%d cexp=%d h=%d stride=%d", p.cin, p.cexp, p.h,

@@ -1,28 +1,35 @@
 // Fused network head for gfx950: Conv2d(3,64,3x3,s2)+BN+PReLU (face_model.py:80) followed by the
-// depthwise 3x3 Conv_block (face_model.py:81) in one kernel.
+// depthwise 3x3 Conv_block (face_model.py:81) in one kernel, reading the caller's crops directly:
+// either the reference's fp32 NCHW tensor in [-1,1] or raw uint8 HWC BGR pixels, in which case
+// ToTensor + Normalize(0.5, 0.5) (facebank.py:22-24) is applied while staging.  Images whose index
+// is >= n_src are the horizontally MIRRORED copies of image (index - n_src): that is the second
+// forward of the flip test-time augmentation (facebank.py:59-61) without a second input tensor.
 //
 // Same structure as the fused block (kernels_block.hip): a workgroup owns TR output rows of one
-// image; the stem conv runs on the matrix cores as an im2col GEMM (K = 27 taps padded to 32, the
-// patch fragments gathered straight from the caller's fp32 NCHW image), its PReLU output goes into
-// an LDS image [row][x+1][64 ch] with zero borders, and every lane then computes the depthwise 3x3
-// for its pixel from nine 16-byte LDS reads per 8 channels and stores NHWC.  The 56x56x64 stem
-// output never touches HBM.
+// image.  It stages the input rows it needs (3 channel planes, 16-bit, zero padded) in LDS with
+// coalesced loads, runs the stem conv on the matrix cores as an im2col GEMM (K = 27 taps padded to
+// 32; a lane gathers its 16 taps from the LDS planes), writes PReLU(stem) into an LDS image
+// [row][x+1][64 ch] with zero borders, and every lane then computes the depthwise 3x3 for its pixel
+// from nine 16-byte LDS reads per 8 channels and stores NHWC.  The 56x56x64 stem output never
+// touches HBM.
 //
 // The stem weight matrix is stored with its rows (output channels) permuted by perm_pos(): MFMA
 // row 16g+8a+4h+i computes output channel 16g+8h+4a+i, so the 8 values a lane holds per
-// 16-channel group are 8 CONSECUTIVE channels and travel as one 16-byte unit.
+// 16-channel group are 8 CONSECUTIVE channels and travel as one 16-byte unit.  Slope arrays hold
+// (PReLU slope - 1).
 #include "common.h"
 
 namespace fra {
 
 __device__ __forceinline__ int eswz2(int slot) { return (slot >> 1) & 7; }   // as eswz() in kernels_block.hip
 
-template <typename T, int TR, int NW, int MINW>
+template <typename T, bool U8, int TR, int NW, int MINW>
 __global__ __launch_bounds__(NW * 64, MINW)
-void stemdw_kernel(const float* __restrict__ X, const T* __restrict__ WA, const float* __restrict__ b1,
+void stemdw_kernel(const void* __restrict__ Xv, int n_src, const T* __restrict__ WA, const float* __restrict__ b1,
                    const float* __restrict__ s1, const T* __restrict__ W2, const float* __restrict__ b2,
                    const float* __restrict__ s2, T* __restrict__ O) {
     typedef typename vec8<T>::type V8;
+    typedef typename vec4<T>::type V4;
     constexpr int NT = NW * 64;
     constexpr int H = 56, W = 56, HI = 112;
     constexpr int RIN = TR + 2, PITCH = W + 2;
@@ -30,24 +37,82 @@ void stemdw_kernel(const float* __restrict__ X, const T* __restrict__ WA, const 
     constexpr int MTI = (PIN + 31) / 32, MTO = (POUT + 31) / 32;
     constexpr int MTIW = (MTI + NW - 1) / NW, MTOW = (MTO + NW - 1) / NW;
     constexpr int ES_BYTES = RIN * PITCH * 128;
-    constexpr int OFF_W2 = ES_BYTES, OFF_B1 = OFF_W2 + 9 * 64 * 2, OFF_S1 = OFF_B1 + 256, OFF_B2 = OFF_S1 + 256,
+    // staged input: 4 planes (3 channels + one all-zero plane for the 5 padding taps) of NR rows x PW columns;
+    // input column x sits at column x + 4, so groups of 4 columns line up with 16-byte source loads
+    constexpr int NR = 2 * TR + 5, PW = 120, NG = PW / 4;
+    constexpr int OFF_IN = ES_BYTES, IN_BYTES = 4 * NR * PW * 2;
+    constexpr int OFF_W2 = OFF_IN + IN_BYTES, OFF_B1 = OFF_W2 + 9 * 64 * 2, OFF_S1 = OFF_B1 + 256, OFF_B2 = OFF_S1 + 256,
                   OFF_S2 = OFF_B2 + 256;
     static_assert(H % TR == 0, "band height");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const es = lds;
+    T* const inp = reinterpret_cast<T*>(lds + OFF_IN);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int band = blockIdx.x, img = blockIdx.y;
+    const int src = img >= n_src ? img - n_src : img;
+    const bool flip = img >= n_src;
     const int y0 = band * TR, row0 = y0 - 1;
+    const int rin0 = 2 * row0 - 1;                 // input row held by LDS input row 0
 
+    // zero the activation image and the padding plane; planes 0-2 are written in full by the staging loop
     for (int i = tid; i < ES_BYTES / 16; i += NT) reinterpret_cast<f32x4*>(es)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < NR * PW * 2 / 16; i += NT)
+        reinterpret_cast<f32x4*>(lds + OFF_IN + 3 * NR * PW * 2)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = tid; i < 9 * 64 / 8; i += NT) reinterpret_cast<V8*>(lds + OFF_W2)[i] = reinterpret_cast<const V8*>(W2)[i];
     if (tid < 16) {
         reinterpret_cast<f32x4*>(lds + OFF_B1)[tid] = reinterpret_cast<const f32x4*>(b1)[tid];
         reinterpret_cast<f32x4*>(lds + OFF_S1)[tid] = reinterpret_cast<const f32x4*>(s1)[tid];
         reinterpret_cast<f32x4*>(lds + OFF_B2)[tid] = reinterpret_cast<const f32x4*>(b2)[tid];
         reinterpret_cast<f32x4*>(lds + OFF_S2)[tid] = reinterpret_cast<const f32x4*>(s2)[tid];
+    }
+
+    // ---- stage the input band: column group g holds input columns 4(g-1) .. 4(g-1)+3 (g = 0 and g = NG-1 are padding)
+    if (!U8) {
+        const float* X = static_cast<const float*>(Xv) + (size_t)src * 3 * HI * HI;
+        for (int i = tid; i < 3 * NR * NG; i += NT) {
+            const int g = i % NG, cr = i / NG;           // cr = c * NR + ry
+            const int ry = cr % NR, c = cr / NR;
+            const int yin = rin0 + ry;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (g >= 1 && g <= 28 && yin >= 0 && yin < HI) {
+                const int x0 = flip ? 108 - 4 * (g - 1) : 4 * (g - 1);
+                v = *reinterpret_cast<const f32x4*>(X + ((size_t)c * HI + yin) * HI + x0);
+                if (flip) v = f32x4{v[3], v[2], v[1], v[0]};
+            }
+            V4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
+            *reinterpret_cast<V4*>(inp + cr * PW + 4 * g) = o;
+        }
+    } else {
+        // uint8 HWC: 4 pixels x 3 channels = 12 contiguous bytes; ToTensor (/255) then Normalize ((t - 0.5) / 0.5)
+        const unsigned char* X = static_cast<const unsigned char*>(Xv) + (size_t)src * HI * HI * 3;
+        for (int i = tid; i < NR * NG; i += NT) {
+            const int g = i % NG, ry = i / NG;
+            const int yin = rin0 + ry;
+            unsigned w0 = 0, w1 = 0, w2 = 0;
+            const bool ok = g >= 1 && g <= 28 && yin >= 0 && yin < HI;
+            if (ok) {
+                const int x0 = flip ? 108 - 4 * (g - 1) : 4 * (g - 1);
+                const unsigned* p = reinterpret_cast<const unsigned*>(X + ((size_t)yin * HI + x0) * 3);
+                w0 = p[0]; w1 = p[1]; w2 = p[2];
+            }
+            const unsigned long long lo = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                V4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int byte = 3 * j + c;          // pixel j, channel c
+                    const unsigned u = byte < 8 ? (unsigned)(lo >> (8 * byte)) & 255u : (w2 >> (8 * (byte - 8))) & 255u;
+                    const float f = ok ? ((float)u / 255.0f - 0.5f) / 0.5f : 0.0f;
+                    o[flip ? 3 - j : j] = (T)f;
+                }
+                *reinterpret_cast<V4*>(inp + (c * NR + ry) * PW + 4 * g) = o;
+            }
+        }
     }
 
     // stem weights as MFMA A fragments: 2 tiles of 32 (permuted) output channels x 2 k-steps
@@ -57,44 +122,35 @@ void stemdw_kernel(const float* __restrict__ X, const T* __restrict__ WA, const 
 #pragma unroll
         for (int s = 0; s < 2; ++s) wa[m][s] = *reinterpret_cast<const V8*>(WA + (32 * m + r) * 32 + 16 * s + 8 * h);
 
-    // the 16 taps this lane gathers: t = 16 s + 8 h + j -> (c, ky, kx); offset inside the 3x112x112 image
+    // the 16 taps this lane gathers: t = 16 s + 8 h + j -> plane c = t / 9 (3 = zero plane), ky, kx;
+    // element offset from the lane's patch origin (LDS row 2 iy, column 2 ix + 3)
     int toff[2][8];
-    unsigned ky0 = 0, kx0 = 0, live = 0;   // bit 8 s + j
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int t = 16 * s + 8 * h + j;
             const int c = t / 9, rem = t - 9 * c, ky = rem / 3, kx = rem - 3 * ky;
-            toff[s][j] = c * HI * HI + ky * HI + kx;
-            if (ky == 0) ky0 |= 1u << (8 * s + j);
-            if (kx == 0) kx0 |= 1u << (8 * s + j);
-            if (t < 27) live |= 1u << (8 * s + j);
+            toff[s][j] = (c * NR + ky) * PW + kx + 3;
         }
     __syncthreads();
 
     // ================= stem: im2col GEMM -> PReLU -> LDS image =================
-    const float* Ximg = X + (size_t)img * 3 * HI * HI;
 #pragma unroll 1
     for (int t = 0; t < MTIW; ++t) {
         if (wave + NW * t >= MTI) break;      // wave-uniform
         const int p = 32 * (wave + NW * t) + r;
-        const int iy = p / W, ix = p - iy * W;
+        const bool inb = p < PIN;
+        const int pc = inb ? p : 0;
+        const int iy = pc / W, ix = pc - iy * W;
         const int gy = row0 + iy;
-        const bool ok = (p < PIN) && (gy >= 0) && (gy < H);
-        const int base = (2 * gy - 1) * HI + (2 * ix - 1);
-        unsigned mask = ok ? live : 0u;
-        if (gy == 0) mask &= ~ky0;            // input row -1 is padding
-        if (ix == 0) mask &= ~kx0;            // input column -1 is padding
+        const bool ok = inb && (gy >= 0) && (gy < H);
+        const T* patch = inp + (2 * iy) * PW + 2 * ix;
         V8 bfr[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bool v = (mask >> (8 * s + j)) & 1u;
-                const float f = v ? Ximg[base + toff[s][j]] : 0.0f;
-                bfr[s][j] = (T)f;
-            }
+            for (int j = 0; j < 8; ++j) bfr[s][j] = patch[toff[s][j]];
         const int slot = iy * PITCH + ix + 1;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -175,26 +231,32 @@ void stemdw_kernel(const float* __restrict__ X, const T* __restrict__ WA, const 
     }
 }
 
-template <typename T, int TR, int NW, int MINW>
-static int launch_stemdw_cfg(const StemDwParams& p, const float* x, void* out, int B, hipStream_t s) {
-    constexpr int lds = (TR + 2) * 58 * 128 + 9 * 64 * 2 + 4 * 256;
-    auto kern = stemdw_kernel<T, TR, NW, MINW>;
+template <typename T, bool U8, int TR, int NW, int MINW>
+static int launch_stemdw_cfg(const StemDwParams& p, const void* x, int n_src, void* out, int B, hipStream_t s) {
+    constexpr int lds = (TR + 2) * 58 * 128 + 4 * (2 * TR + 5) * 120 * 2 + 9 * 64 * 2 + 4 * 256;
+    auto kern = stemdw_kernel<T, U8, TR, NW, MINW>;
     static bool attr_done = false;
     if (!attr_done) {
         FRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(56 / TR, B), dim3(NW * 64), lds, s, x, (const T*)p.wa, p.b1, p.s1, (const T*)p.w2, p.b2,
-                       p.s2, (T*)out);
+    hipLaunchKernelGGL(kern, dim3(56 / TR, B), dim3(NW * 64), lds, s, x, n_src, (const T*)p.wa, p.b1, p.s1, (const T*)p.w2,
+                       p.b2, p.s2, (T*)out);
     FRA_HIP(hipGetLastError());
     return FRA_OK;
 }
 
-int launch_stemdw(int dt, const StemDwParams& p, const float* x, void* out, int B, hipStream_t s) {
+int launch_stemdw(int dt, const StemDwParams& p, const void* x, int x_is_u8, int n_src, void* out, int B,
+                  hipStream_t s) {
     FRA_REQUIRE(x && out && p.wa && p.b1 && p.s1 && p.w2 && p.b2 && p.s2, FRA_ERR_ARG, "stemdw: null pointer");
     FRA_REQUIRE(B > 0 && B <= 65535, FRA_ERR_ARG, "stemdw: batch %d not in [1,65535]", B);
-    if (dt == ACT_F16) return launch_stemdw_cfg<f16, 4, 4, 3>(p, x, out, B, s);
-    if (dt == ACT_BF16) return launch_stemdw_cfg<bf16, 4, 4, 3>(p, x, out, B, s);
+    FRA_REQUIRE(n_src > 0 && n_src <= B && B <= 2 * n_src, FRA_ERR_ARG, "stemdw: %d images from %d sources", B, n_src);
+    if (dt == ACT_F16)
+        return x_is_u8 ? launch_stemdw_cfg<f16, true, 4, 8, 4>(p, x, n_src, out, B, s)
+                       : launch_stemdw_cfg<f16, false, 4, 8, 4>(p, x, n_src, out, B, s);
+    if (dt == ACT_BF16)
+        return x_is_u8 ? launch_stemdw_cfg<bf16, true, 4, 8, 4>(p, x, n_src, out, B, s)
+                       : launch_stemdw_cfg<bf16, false, 4, 8, 4>(p, x, n_src, out, B, s);
     FRA_REQUIRE(false, FRA_ERR_ARG, "stemdw: unsupported activation dtype %d", dt);
     return FRA_ERR_ARG;
 }

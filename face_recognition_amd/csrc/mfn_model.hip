@@ -402,27 +402,32 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
 // workspace layout for a slice of `b` images: the five buffers back to back, 256-byte aligned
 struct WsPlan {
     size_t off[NBUF];
+    size_t emb;      // f32 [b][E] pre-combine embeddings (flip-TTA only)
     size_t total;
 };
-static WsPlan plan_ws(int b) {
+static WsPlan plan_ws(int b, int E, bool tta) {
     WsPlan p;
     size_t off = 0;
     for (int i = 0; i < NBUF; ++i) {
         p.off[i] = off;
         off = align_up(off + (size_t)kBufElems[i] * 2 * (size_t)b, 256);
     }
+    p.emb = off;
+    if (tta) off = align_up(off + (size_t)b * E * 4, 256);
     p.total = off;
     return p;
 }
 
 static int slice_size(const mfn_handle* h, int B) { return (h->chunk > 0 && h->chunk < B) ? h->chunk : B; }
 
-static int run_op(const mfn_handle* h, const Op& o, const float* x, float* out, char* ws, const WsPlan& p, int b,
-                  hipStream_t s) {
+// b = images in the activation buffers; x holds n_src source crops (b == n_src, or 2 n_src with mirrored copies)
+static int run_op(const mfn_handle* h, const Op& o, const void* x, int x_is_u8, int n_src, float* out, char* ws,
+                  const WsPlan& p, int b, hipStream_t s) {
     auto buf = [&](int id) -> void* { return ws + p.off[id]; };
     switch (o.kind) {
         case OP_STEM:
-            return launch_stem(h->dt, x, (const float*)o.w, o.bias, o.slope, buf(o.out), b, s);
+            FRA_REQUIRE(!x_is_u8 && b == n_src, FRA_ERR_STATE, "uint8 input and fused flip-TTA need the fused schedule");
+            return launch_stem(h->dt, (const float*)x, (const float*)o.w, o.bias, o.slope, buf(o.out), b, s);
         case OP_DW:
             return launch_dw3x3(h->dt, buf(o.in), o.w, o.bias, o.slope, buf(o.out), b, o.hin, o.hin, o.cin, o.stride, s);
         case OP_PW:
@@ -435,28 +440,30 @@ static int run_op(const mfn_handle* h, const Op& o, const float* x, float* out, 
         case OP_BLOCK:
             return launch_block(h->dt, o.bp, buf(o.in), buf(o.out), b, s);
         case OP_STEMDW:
-            return launch_stemdw(h->dt, o.sp, x, buf(o.out), b, s);
+            return launch_stemdw(h->dt, o.sp, x, x_is_u8, n_src, buf(o.out), b, s);
     }
     return FRA_ERR_ARG;
 }
 
-static int check_forward_args(const mfn_handle* h, const float* x, int B, const void* out, const void* ws,
+static int check_forward_args(const mfn_handle* h, const void* x, int B, bool tta, const void* out, const void* ws,
                               size_t ws_bytes) {
     FRA_REQUIRE(h != nullptr, FRA_ERR_ARG, "null handle");
     FRA_REQUIRE(h->loaded, FRA_ERR_STATE, "mfn_forward called before mfn_load_weights");
     FRA_REQUIRE(x && out && ws, FRA_ERR_ARG, "mfn_forward: null pointer");
     FRA_REQUIRE(B > 0, FRA_ERR_ARG, "mfn_forward: batch %d", B);
-    const size_t need = plan_ws(slice_size(h, B)).total;
+    const int sl0 = slice_size(h, B);
+    const size_t need = plan_ws(tta ? 2 * sl0 : sl0, h->E, tta).total;
     FRA_REQUIRE(ws_bytes >= need, FRA_ERR_WORKSPACE, "workspace has %zu bytes, batch %d needs %zu", ws_bytes, B, need);
     FRA_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0, FRA_ERR_ARG,
                 "mfn_forward: workspace must be 256-byte aligned, input/output 16-byte aligned");
     return FRA_OK;
 }
 
-static int forward(mfn_handle* h, const float* x, int B, float* out, void* ws, size_t ws_bytes, hipStream_t s,
-                   float* op_ms, int n_ops_timed) {
-    int rc = check_forward_args(h, x, B, out, ws, ws_bytes);
+static int forward(mfn_handle* h, const void* x, int x_is_u8, int B, bool tta, float* out, void* ws, size_t ws_bytes,
+                   hipStream_t s, float* op_ms, int n_ops_timed) {
+    int rc = check_forward_args(h, x, B, tta, out, ws, ws_bytes);
     if (rc) return rc;
+    FRA_REQUIRE(h->fused || (!tta && !x_is_u8), FRA_ERR_STATE, "uint8 input and fused flip-TTA need the fused schedule");
     const int nops = (int)h->ops().size();
     const int sl = slice_size(h, B);
     std::vector<hipEvent_t> ev;
@@ -467,14 +474,21 @@ static int forward(mfn_handle* h, const float* x, int B, float* out, void* ws, s
         for (auto& e : ev) FRA_HIP(hipEventCreate(&e));
     }
     for (int b0 = 0; b0 < B; b0 += sl) {
-        const int b = (B - b0) < sl ? (B - b0) : sl;
-        const WsPlan p = plan_ws(b);
-        const float* xs = x + (size_t)b0 * 3 * 112 * 112;
+        const int b = (B - b0) < sl ? (B - b0) : sl;      // source crops in this slice
+        const int nb = tta ? 2 * b : b;                   // images in flight (second half: mirrored copies)
+        const WsPlan p = plan_ws(nb, h->E, tta);
+        const void* xs = x_is_u8 ? static_cast<const void*>(static_cast<const unsigned char*>(x) + (size_t)b0 * 3 * 112 * 112)
+                                 : static_cast<const void*>(static_cast<const float*>(x) + (size_t)b0 * 3 * 112 * 112);
         float* os = out + (size_t)b0 * h->E;
+        float* emb = tta ? reinterpret_cast<float*>(static_cast<char*>(ws) + p.emb) : os;
         if (op_ms) FRA_HIP(hipEventRecord(ev[0], s));
         for (int i = 0; i < nops; ++i) {
-            rc = run_op(h, h->ops()[i], xs, os, static_cast<char*>(ws), p, b, s);
+            rc = run_op(h, h->ops()[i], xs, x_is_u8, b, emb, static_cast<char*>(ws), p, nb, s);
             if (rc) return rc;
+            if (i == nops - 1 && tta) {   // l2_norm(emb + emb_mirror): facebank.py:62
+                rc = launch_add_l2norm(emb, emb + (size_t)b * h->E, os, b, h->E, s);
+                if (rc) return rc;
+            }
             if (op_ms) FRA_HIP(hipEventRecord(ev[i + 1], s));
         }
         if (op_ms) {
@@ -523,7 +537,14 @@ int mfn_load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
 
 int mfn_workspace_bytes(const mfn_handle* h, int max_batch, size_t* bytes) {
     FRA_REQUIRE(h && bytes && max_batch > 0, FRA_ERR_ARG, "mfn_workspace_bytes: bad argument");
-    *bytes = plan_ws(slice_size(h, max_batch)).total;
+    *bytes = plan_ws(slice_size(h, max_batch), h->E, false).total;
+    return FRA_OK;
+}
+
+int mfn_workspace_bytes_ex(const mfn_handle* h, int max_batch, int tta, size_t* bytes) {
+    FRA_REQUIRE(h && bytes && max_batch > 0, FRA_ERR_ARG, "mfn_workspace_bytes_ex: bad argument");
+    const int sl = slice_size(h, max_batch);
+    *bytes = plan_ws(tta ? 2 * sl : sl, h->E, tta != 0).total;
     return FRA_OK;
 }
 
@@ -540,13 +561,20 @@ int mfn_set_fused(mfn_handle* h, int fused) {
 }
 
 int mfn_forward(mfn_handle* h, const float* x, int B, float* out, void* ws, size_t ws_bytes, fra_stream stream) {
-    return forward(h, x, B, out, ws, ws_bytes, (hipStream_t)stream, nullptr, 0);
+    return forward(h, x, 0, B, false, out, ws, ws_bytes, (hipStream_t)stream, nullptr, 0);
+}
+
+int mfn_forward_ex(mfn_handle* h, const void* x, int input_format, int B, int tta, float* out, void* ws,
+                   size_t ws_bytes, fra_stream stream) {
+    FRA_REQUIRE(input_format == 0 || input_format == 1, FRA_ERR_ARG, "mfn_forward_ex: input_format %d (0 = f32 NCHW, 1 = u8 HWC)",
+                input_format);
+    return forward(h, x, input_format, B, tta != 0, out, ws, ws_bytes, (hipStream_t)stream, nullptr, 0);
 }
 
 int mfn_forward_timed(mfn_handle* h, const float* x, int B, float* out, void* ws, size_t ws_bytes, fra_stream stream,
                       float* op_ms, int n_ops) {
     FRA_REQUIRE(op_ms != nullptr, FRA_ERR_ARG, "mfn_forward_timed: null op_ms");
-    return forward(h, x, B, out, ws, ws_bytes, (hipStream_t)stream, op_ms, n_ops);
+    return forward(h, x, 0, B, false, out, ws, ws_bytes, (hipStream_t)stream, op_ms, n_ops);
 }
 
 int mfn_op_count(const mfn_handle* h) { return h ? (int)h->ops().size() : -1; }
@@ -568,15 +596,15 @@ int mfn_op_info(const mfn_handle* h, int op, char* name, int name_cap, int* kind
 
 int mfn_debug_prefix(mfn_handle* h, const float* x, int B, int n_ops, float* out_f32, int64_t* numel_per_image,
                      void* ws, size_t ws_bytes, fra_stream stream) {
-    int rc = check_forward_args(h, x, B, out_f32, ws, ws_bytes);
+    int rc = check_forward_args(h, x, B, false, out_f32, ws, ws_bytes);
     if (rc) return rc;
     FRA_REQUIRE(n_ops >= 1 && n_ops < (int)h->ops().size(), FRA_ERR_ARG,
                 "mfn_debug_prefix: n_ops %d not in [1,%d)", n_ops, (int)h->ops().size());
     FRA_REQUIRE(slice_size(h, B) == B, FRA_ERR_STATE, "mfn_debug_prefix: batch chunking must be off");
-    const WsPlan p = plan_ws(B);
+    const WsPlan p = plan_ws(B, h->E, false);
     hipStream_t s = (hipStream_t)stream;
     for (int i = 0; i < n_ops; ++i) {
-        rc = run_op(h, h->ops()[i], x, nullptr, static_cast<char*>(ws), p, B, s);
+        rc = run_op(h, h->ops()[i], x, 0, B, nullptr, static_cast<char*>(ws), p, B, s);
         if (rc) return rc;
     }
     const Op& o = h->ops()[n_ops - 1];

@@ -181,9 +181,9 @@ class MobileFaceNet(nn.Module):
             self._dirty = False
         return lib
 
-    def _ensure_workspace(self, lib, batch: int, device: torch.device) -> torch.Tensor:
+    def _ensure_workspace(self, lib, batch: int, device: torch.device, tta: bool = False) -> torch.Tensor:
         need = C.c_size_t()
-        _lib.check(lib.mfn_workspace_bytes(self._handle, batch, C.byref(need)), "mfn_workspace_bytes")
+        _lib.check(lib.mfn_workspace_bytes_ex(self._handle, batch, int(tta), C.byref(need)), "mfn_workspace_bytes_ex")
         ws = self._workspace
         if ws is None or ws.device != device or ws.numel() < need.value:
             self._workspace = None
@@ -204,13 +204,13 @@ class MobileFaceNet(nn.Module):
             raise RuntimeError("empty batch")
         return x.detach().to(torch.float32).contiguous()
 
-    def workspace_bytes(self, batch: int, device=None) -> int:
+    def workspace_bytes(self, batch: int, device=None, tta: bool = False) -> int:
         """Bytes of scratch a forward of ``batch`` crops needs (for callers that bring their own workspace)."""
         dev = torch.device(device) if device is not None else next(self.parameters()).device
         with torch.cuda.device(dev):
             lib = self._ensure_handle(dev)
             need = C.c_size_t()
-            _lib.check(lib.mfn_workspace_bytes(self._handle, batch, C.byref(need)), "mfn_workspace_bytes")
+            _lib.check(lib.mfn_workspace_bytes_ex(self._handle, batch, int(tta), C.byref(need)), "mfn_workspace_bytes_ex")
         return int(need.value)
 
     def forward(self, x: torch.Tensor, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -226,9 +226,39 @@ class MobileFaceNet(nn.Module):
                                        ws.numel(), _lib.current_stream_ptr(dev)), "mfn_forward")
         return out
 
-    def embed_tta(self, x: torch.Tensor) -> torch.Tensor:
-        """``l2_norm(net(x) + net(hflip(x)))`` -- the flip test-time augmentation of facebank.py:59-62."""
-        return tta_combine(self.forward(x), self.forward(torch.flip(x, dims=[3])))
+    def _forward_ex(self, x: torch.Tensor, fmt: int, tta: bool, workspace: Optional[torch.Tensor]) -> torch.Tensor:
+        dev = x.device
+        with torch.cuda.device(dev):
+            lib = self._ensure_handle(dev)
+            ws = workspace if workspace is not None else self._ensure_workspace(lib, x.shape[0], dev, tta)
+            out = torch.empty((x.shape[0], self.embedding_size), dtype=torch.float32, device=dev)
+            _lib.check(lib.mfn_forward_ex(self._handle, x.data_ptr(), fmt, x.shape[0], int(tta), out.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev)), "mfn_forward_ex")
+        return out
+
+    def embed_tta(self, x: torch.Tensor, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``l2_norm(net(x) + net(hflip(x)))`` -- the flip test-time augmentation of facebank.py:59-62.
+        With the fused schedule the mirrored forward reads ``x`` backwards inside the first kernel; no
+        flipped copy of the input is made."""
+        if not self._fused:
+            return tta_combine(self.forward(x), self.forward(torch.flip(x, dims=[3])))
+        return self._forward_ex(self._check_input(x), 0, True, workspace)
+
+    def forward_u8(self, x_u8: torch.Tensor, tta: bool = False, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Embed raw crops: ``x_u8`` uint8 [B,112,112,3] HWC BGR on the HIP device (what cv2.imread /
+        Face_alignment return, stacked).  Equivalent to ``net(test_transform(img))`` per crop with
+        ToTensor + Normalize(0.5, 0.5) (facebank.py:22-24) computed inside the first kernel."""
+        if self.training:
+            raise RuntimeError("MobileFaceNet (face_recognition_amd) is inference-only: call .eval() first")
+        if not (isinstance(x_u8, torch.Tensor) and x_u8.dtype == torch.uint8 and x_u8.dim() == 4
+                and tuple(x_u8.shape[1:]) == (L.INPUT_HW, L.INPUT_HW, 3)):
+            raise RuntimeError(f"expected uint8 [B,112,112,3], got {getattr(x_u8, 'dtype', None)} "
+                               f"{tuple(getattr(x_u8, 'shape', ()))}")
+        if not x_u8.is_cuda or x_u8.shape[0] == 0:
+            raise RuntimeError("forward_u8 needs a non-empty tensor on the HIP device")
+        if not self._fused:
+            raise RuntimeError("forward_u8 needs the fused schedule (set_fused(True))")
+        return self._forward_ex(x_u8.detach().contiguous(), 1, tta, workspace)
 
     def forward_timed(self, x: torch.Tensor):
         """(embeddings, per-op milliseconds, op table) -- benchmark helper, synchronises."""

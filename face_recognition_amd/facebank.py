@@ -201,7 +201,7 @@ def prepare_facebank(model: MobileFaceNet, path: str = "facebank", tta: bool = T
     for doc in data_path.iterdir():
         if doc.is_file():
             continue
-        crops = []
+        crops = []      # uint8 HWC BGR crops; ToTensor + Normalize happen inside the first kernel
         for files in listdir_nohidden(doc):
             img = _imread_bgr(os.path.join(doc, files))
             if img is None:
@@ -211,12 +211,12 @@ def prepare_facebank(model: MobileFaceNet, path: str = "facebank", tta: bool = T
                     raise RuntimeError(f"{os.path.join(doc, files)} is {img.shape}, not a 112x112 aligned crop; "
                                        "pass align_fn (e.g. the reference's MTCNN + Face_alignment)")
                 img = align_fn(img)
-            crops.append(test_transform(img, device))
+            crops.append(np.ascontiguousarray(img, dtype=np.uint8))
         if len(crops) == 0:
             continue
-        x = torch.stack(crops)
+        x = torch.from_numpy(np.stack(crops)).to(device)
         with torch.no_grad():
-            embs = model.embed_tta(x) if tta else model(x)
+            embs = model.forward_u8(x, tta=tta)
         embeddings.append(embs.mean(0, keepdim=True))
         names.append(doc.name)
     embeddings = torch.cat(embeddings)

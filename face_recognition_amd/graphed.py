@@ -40,13 +40,12 @@ class GraphedRecognizer:
             self.gallery = targets if isinstance(targets, Gallery) else Gallery(targets, store="f32", device=self.device)
             self.gallery.reserve(max_batch)      # no scratch growth (= no stale pointers) once graphs exist
         # a workspace of our own: the module's grows (and moves) with eager calls of other sizes
-        self._ws = torch.empty(model.workspace_bytes(max_batch, self.device), dtype=torch.uint8, device=self.device)
+        self._ws = torch.empty(model.workspace_bytes(max_batch, self.device, tta=tta), dtype=torch.uint8,
+                               device=self.device)
         self._graphs: Dict[int, _Captured] = {}
 
     def _run(self, x):
-        emb = self.model(x, workspace=self._ws)
-        if self.tta:
-            emb = tta_combine(emb, self.model(torch.flip(x, dims=[3]), workspace=self._ws))
+        emb = self.model.embed_tta(x, workspace=self._ws) if self.tta else self.model(x, workspace=self._ws)
         match = match_facebank(emb, self.gallery, self.threshold) if self.gallery is not None else None
         return emb, match
 

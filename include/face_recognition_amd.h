@@ -75,6 +75,16 @@ int mfn_set_fused(mfn_handle* h, int fused);
 int mfn_forward(mfn_handle* h, const float* x_nchw, int B, float* out, void* workspace, size_t workspace_bytes,
                 fra_stream stream);
 
+/* Extended forward.  input_format 0: x is f32 [B,3,112,112] NCHW in [-1,1] (as mfn_forward);
+ * input_format 1: x is uint8 [B,112,112,3] HWC BGR pixels as cv2.imread / Face_alignment produce them, and
+ * ToTensor + Normalize([.5]*3,[.5]*3) (facebank.py:22-24, cam_demo.py:83-85) is applied inside the first kernel.
+ * tta != 0: out[b] = l2_norm(net(x[b]) + net(hflip(x[b]))), the flip test-time augmentation of
+ * facebank.py:59-62 / cam_demo.py:88-92 / Evaluation.py:50-52, with the mirrored read done inside the
+ * first kernel (no second input tensor); needs mfn_workspace_bytes_ex(..., tta=1).  Fused schedule only. */
+int mfn_forward_ex(mfn_handle* h, const void* x, int input_format, int B, int tta, float* out, void* workspace,
+                   size_t workspace_bytes, fra_stream stream);
+int mfn_workspace_bytes_ex(const mfn_handle* h, int max_batch, int tta, size_t* bytes);
+
 /* Same forward, bracketing every kernel with events on `stream`; synchronises; op_ms[i] receives
  * the milliseconds of op i (see mfn_op_count / mfn_op_info).  For benchmarks only. */
 int mfn_forward_timed(mfn_handle* h, const float* x_nchw, int B, float* out, void* workspace,

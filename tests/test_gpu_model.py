@@ -150,3 +150,67 @@ def test_errors(hip_model, device):
             hip_model(torch.zeros((1, 3, 112, 112), device=device))
     finally:
         hip_model.eval()
+
+
+def _u8_crops(n, seed):
+    rng = np.random.default_rng(seed)
+    coarse = rng.integers(0, 256, (n, 14, 14, 3), dtype=np.uint8)
+    img = np.repeat(np.repeat(coarse, 8, 1), 8, 2).astype(np.int16) + rng.integers(-20, 21, (n, 112, 112, 3))
+    return np.clip(img, 0, 255).astype(np.uint8)            # HWC, BGR like cv2.imread
+
+
+def _transform(u8):
+    """ToTensor + Normalize(0.5, 0.5) of facebank.py:22-24 on a uint8 HWC batch -> f32 NCHW."""
+    t = torch.from_numpy(u8).permute(0, 3, 1, 2).to(torch.float32).div(255)
+    return (t - 0.5) / 0.5
+
+
+@pytest.mark.parametrize("B", [1, 6])
+def test_uint8_input_and_fused_tta(hip_model, device, state_dict_np, B):
+    """Raw uint8 HWC crops with the transform fused into the first kernel, and the flip-TTA with the
+    mirrored read fused as well, against the oracle on the explicitly transformed / flipped tensors."""
+    u8 = _u8_crops(B, 40 + B)
+    x = _transform(u8)
+    want = ref.forward(state_dict_np, x).numpy()
+    want_tta = ref.embed_tta(state_dict_np, x).numpy()
+    xd = torch.from_numpy(u8).to(device)
+    got = hip_model.forward_u8(xd).cpu().numpy()
+    got_tta = hip_model.forward_u8(xd, tta=True).cpu().numpy()
+    assert cosine_rows(got, want).min() >= COS_BAR
+    assert cosine_rows(got_tta, want_tta).min() >= COS_BAR
+    # the f32 entry point on the transformed tensor gives the same embeddings as the uint8 entry point
+    same = hip_model(x.to(device)).cpu().numpy()
+    assert np.abs(same - got).max() < 2e-3 and cosine_rows(same, got).min() >= 0.99999
+    # fused flip == explicit flip through the plain forward
+    flipped = hip_model(torch.flip(x, dims=[3]).to(device)).cpu()
+    manual = ((torch.from_numpy(same) + flipped) / (torch.from_numpy(same) + flipped).norm(dim=1, keepdim=True)).numpy()
+    assert cosine_rows(hip_model.embed_tta(x.to(device)).cpu().numpy(), manual).min() >= 0.99999
+    with pytest.raises(RuntimeError):
+        hip_model.forward_u8(xd.float())
+
+
+def test_prepare_facebank_from_image_folders(hip_model, device, state_dict_np, tmp_path):
+    """Enrolment (facebank.py:33-77): per-identity mean of TTA embeddings, not re-normalised; names[0] == '';
+    files written in the reference's format and readable by load_facebank."""
+    from PIL import Image
+
+    from face_recognition_amd.facebank import load_facebank, match_facebank, prepare_facebank
+    people = {"alice": _u8_crops(3, 1), "bob": _u8_crops(1, 2), "carol": _u8_crops(2, 3)}
+    for name, crops in people.items():
+        (tmp_path / name).mkdir()
+        for i, c in enumerate(crops):
+            Image.fromarray(c[:, :, ::-1]).save(tmp_path / name / f"{i}.png")      # file is RGB, reader returns BGR
+    (tmp_path / "notes.txt").write_text("files at the top level are skipped")
+    (tmp_path / "alice" / ".hidden").write_text("hidden files are skipped")
+    os.remove(tmp_path / "alice" / ".hidden")
+    emb, names = prepare_facebank(hip_model, path=str(tmp_path), tta=True)
+    assert names[0] == "" and sorted(names[1:]) == sorted(people) and emb.shape == (3, 512)
+    for row, name in zip(emb.cpu().numpy(), names[1:]):
+        want = ref.embed_tta(state_dict_np, _transform(people[name])).mean(0).numpy()
+        assert cosine_rows(row[None], want[None]).min() >= COS_BAR
+        assert abs(np.linalg.norm(row) - np.linalg.norm(want)) < 2e-3            # mean of unit rows: norm <= 1
+    emb2, names2 = load_facebank(str(tmp_path))
+    assert torch.equal(emb2.cpu(), emb.cpu()) and list(names2) == list(names)
+    q = hip_model.forward_u8(torch.from_numpy(people["bob"]).to(device), tta=True)
+    mn, idx, _ = match_facebank(q, emb, threshold=60)
+    assert names[int(idx[0]) + 1] == "bob" and float(mn[0]) < 1e-3
