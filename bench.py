@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--search-steps", type=int, default=3)
     ap.add_argument("--unfused", action="store_true", help="one kernel per conv instead of one per block")
     ap.add_argument("--no-search", action="store_true")
+    ap.add_argument("--search-only", action="store_true", help="skip the forward timing (profiling aid)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -242,6 +243,11 @@ def main():
     g.manual_seed(1000 + rank)
     x = (torch.randint(0, 256, (B, 3, 112, 112), generator=g, device=dev).float() / 255.0 - 0.5) / 0.5
 
+    if args.search_only:
+        s = run_search(args, rank, world, dev, dist)
+        if rank == 0:
+            print(json.dumps(s), flush=True)
+        return
     for _ in range(args.warmup):
         y = net(x)
     torch.cuda.synchronize()

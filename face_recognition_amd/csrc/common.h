@@ -31,6 +31,12 @@ __device__ __forceinline__ f32x16 mfma32(vec8<bf16>::type a, vec8<bf16>::type b,
 }
 
 // row of the 32x32 accumulator tile held in register g by a lane of half h
+__device__ __forceinline__ f32x4 mfma16(vec8<f16>::type a, vec8<f16>::type b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(vec8<bf16>::type a, vec8<bf16>::type b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 __device__ __forceinline__ int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 
 // ---- error plumbing -------------------------------------------------------------------------

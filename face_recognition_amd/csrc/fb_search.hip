@@ -16,7 +16,7 @@
 struct fb_handle {
     int device = 0;
     int64_t N = 0;      // rows
-    int64_t Npad = 0;   // rows allocated (multiple of 64 for the packed layout)
+    int64_t Npad = 0;   // rows allocated (a whole number of search tiles for the packed layout)
     int D = 0;
     int store = 0;      // FRA_F32 / FRA_BF16 / FRA_F16
     int64_t index_base = 0;
@@ -34,7 +34,7 @@ namespace fra {
 
 static const int SEARCH_D = 512;   // feature width of the MFMA search kernel
 static const int BQ = 256;         // queries per block (8 waves x 32)
-static const int BG = 64;          // gallery rows per LDS tile
+static const int BG = 48;          // gallery rows per LDS tile
 
 // ------------------------------------------------------------------------------------------------
 // pack: f32 rows -> 16-bit rows + (-|g|^2/2) of the ROUNDED values.  One wave per row.
@@ -85,12 +85,26 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// MFMA search.  Block = 8 waves; wave w owns queries [q0 + 32 w, +32) whose fragments stay in
-// registers for the whole kernel (32 k-steps x 4 VGPRs).  Gallery tiles of 64 rows (64 KB, plus
-// their 64 bias terms) arrive in LDS by direct global->LDS loads, double buffered; the 16-byte
+// MFMA search.  Block = 8 waves; wave w owns queries [q0 + 32 w, +32) as two 16-query tiles whose
+// 16x16x32 B fragments stay in registers for the whole kernel (16 k-steps x 2 tiles x 4 VGPRs).
+// Gallery tiles of 48 rows (48 KB, plus their 48 bias terms) arrive in LDS by direct global->LDS
+// loads through a ring of three buffers, two tiles ahead of the one being consumed; the 16-byte
 // chunk c of row r sits at chunk position c ^ (r & 15), applied on the global source address
 // because the LDS side of such a load is lane-linear.
-// Each lane keeps KS (score, row) pairs, best first, for its query and its half of the rows.
+//
+// A tile is consumed as three chains of 16 rows; chain rt accumulates rows 16 rt .. +16 against both
+// query tiles over the 16 k-steps.  Lane (col = lane & 15, kg = lane >> 4) then holds, for query
+// col of each tile, the scores of rows 16 rt + 4 kg + i (i < 4), and keeps a running top-KS list per
+// query tile for that quarter of the rows.  The list update of a chain is issued inside the next
+// chain (three accumulator sets rotate), so its vector work overlaps matrix work.
+//
+// The LDS reads and their waits are written by hand: reads run PD steps ahead of the MFMAs through a
+// ring of NB register slots -- across tile boundaries too -- and since LDS returns data in order,
+// "at most n reads outstanding" (s_waitcnt lgkmcnt(n)) is exactly "the fragment of this step has
+// arrived".  The one barrier per tile sits PD steps before the tile's end, just ahead of the first
+// read of the next tile, so the matrix pipeline never drains at a tile boundary.  The buffer a
+// tile occupies is overwritten by loads that any wave issues only after that barrier plus several
+// steps, when every read of the tile has long been issued and returned.
 // ------------------------------------------------------------------------------------------------
 typedef const __attribute__((address_space(1))) void* GPTR;  // global source of an LDS-DMA load
 typedef __attribute__((address_space(3))) void* LPTR;        // its (wave-uniform) LDS destination
@@ -115,6 +129,127 @@ template <int KS> struct TopList {
     }
 };
 
+static const int SEARCH_KSTEPS = SEARCH_D / 32;                  // k-steps of one chain
+static const int SEARCH_CHAINS = BG / 16;                        // chains of one tile (3)
+static const int SEARCH_STEPS = SEARCH_CHAINS * SEARCH_KSTEPS;   // steps of one tile
+static const int SEARCH_PIECES = BG / 8;                         // 1 KB rows each wave stages per tile
+static const int SEARCH_TILE_BYTES = BG * SEARCH_D * 2;          // 49152
+static const int SEARCH_BUF_BYTES = SEARCH_TILE_BYTES + 256;     // + bias terms (a 64-lane load fills 256 B)
+
+// NB = A-fragment register slots (a divisor of SEARCH_STEPS so the ring carries across tiles);
+// reads run PD = NB - 1 steps ahead
+template <typename T, int KS, int NB> struct SearchCtx {
+    typedef typename vec8<T>::type V8;
+    V8 qf[SEARCH_KSTEPS][2];       // query fragments
+    V8 af[NB];                     // ring of gallery fragments
+    f32x4 acc[SEARCH_CHAINS][2];   // [chain][query tile]
+    f32x4 bias;                    // -|g|^2/2 of the chain's 4 rows of this lane
+    TopList<KS> top[2];            // per query tile
+    int bl[4], bn[4];              // lane part of the fragment address for k-step & 3: this tile, next tile
+    int nha, nhn;                  // LDS address of this lane's bias terms of chain 0: this tile, next tile
+    int kg;
+    // staging of the tile two ahead
+    const T* gsrc;                 // this lane's source of piece 0 (even pieces)
+    const T* gsrc_odd;             // same for odd pieces (the swizzle differs by one bit)
+    const float* nsrc;             // bias source (wave 0)
+    char* ldst;                    // LDS destination of piece 0
+    int wave;
+    bool do_stage;
+};
+
+// fold chain `rt` of the tile whose first row is row0 into the lists
+template <typename Ctx, int KS>
+__device__ __forceinline__ void fold_chain(Ctx& c, int row0, int rt) {
+    const float m0 = fmaxf(fmaxf(c.acc[rt][0][0], c.acc[rt][0][1]), fmaxf(c.acc[rt][0][2], c.acc[rt][0][3]));
+    const float m1 = fmaxf(fmaxf(c.acc[rt][1][0], c.acc[rt][1][1]), fmaxf(c.acc[rt][1][2], c.acc[rt][1][3]));
+    if (__any(m0 > c.top[0].s[KS - 1] || m1 > c.top[1].s[KS - 1])) {
+        const int rbase = row0 + 16 * rt + 4 * c.kg;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = c.acc[rt][u][i];
+                if (v > c.top[u].s[KS - 1]) c.top[u].insert(v, rbase + i);
+            }
+    }
+}
+
+template <typename T, int KS, int NB, int S> struct SearchSteps {
+    typedef typename vec8<T>::type V8;
+    typedef SearchCtx<T, KS, NB> Ctx;
+    static constexpr int PD = NB - 1;
+    static constexpr int BARRIER_STEP = SEARCH_STEPS - PD - 1;   // the step after which the next tile is first read
+    static constexpr int PIECES_BEFORE_BARRIER = (BARRIER_STEP - 3) / 8 + 1;   // pieces go out at steps 8 p + 3
+    static_assert(SEARCH_STEPS % NB == 0, "ring slots must line up across tiles");
+    static_assert(8 * (SEARCH_PIECES - 1) + 3 < SEARCH_STEPS, "every piece needs a step");
+    // reads issued after the fragment of step ss and before its wait: the PD fragments that follow
+    // (into the next tile if need be) plus the bias reads that precede a chain's first fragment
+    static constexpr int ahead(int ss) {
+        int n = PD;
+        for (int m = SEARCH_KSTEPS; m <= SEARCH_STEPS; m += SEARCH_KSTEPS)
+            if (ss < m && m <= ss + PD) ++n;
+        return n;
+    }
+    // LIN = step index counted from the start of this tile; LIN >= STEPS addresses the next tile
+    template <int LIN> static __device__ __forceinline__ void read_step(Ctx& c) {
+        constexpr bool nxt = LIN >= SEARCH_STEPS;
+        constexpr int SS = nxt ? LIN - SEARCH_STEPS : LIN;
+        constexpr int rt = SS / SEARCH_KSTEPS, ks = SS % SEARCH_KSTEPS;
+        if constexpr (ks == 0)   // the chain's bias terms go first: they are needed with its first fragment
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c.bias) : "v"(nxt ? c.nhn : c.nha), "n"(rt * 64));
+        asm volatile("ds_read_b128 %0, %1 offset:%2"
+                     : "=v"(c.af[LIN % NB])
+                     : "v"(nxt ? c.bn[ks & 3] : c.bl[ks & 3]), "n"((ks >> 2) * 256 + rt * 16384));
+    }
+    static __device__ __forceinline__ void prologue(Ctx& c) {
+        if constexpr (S < PD) {
+            read_step<S>(c);
+            SearchSteps<T, KS, NB, S + 1>::prologue(c);
+        }
+    }
+    // one piece (a 1 KB row) of the tile two ahead; wave w stages rows w, w + 8, ...
+    template <int PIECE> static __device__ __forceinline__ void stage_piece(Ctx& c) {
+        if (c.do_stage) {
+            constexpr int row8 = PIECE * 8;
+            __builtin_amdgcn_global_load_lds((GPTR)(((PIECE & 1) ? c.gsrc_odd : c.gsrc) + (size_t)row8 * SEARCH_D),
+                                             (LPTR)(c.ldst + row8 * (SEARCH_D * 2)), 16, 0, 0);
+            if (PIECE == SEARCH_PIECES - 1 && c.wave == 0)   // wave 0: ldst is the buffer base
+                __builtin_amdgcn_global_load_lds((GPTR)c.nsrc, (LPTR)(c.ldst + SEARCH_TILE_BYTES), 4, 0, 0);
+        }
+    }
+    static __device__ __forceinline__ void run(Ctx& c, int row0, bool have_prev) {
+        if constexpr (S < SEARCH_STEPS) {
+            constexpr int rt = S / SEARCH_KSTEPS, ks = S % SEARCH_KSTEPS, slot = S % NB;
+            read_step<S + PD>(c);
+            if constexpr (ks == 0) {
+                // wait for this step's fragment and the chain's bias; both are named so that their
+                // consumers cannot be moved above the wait
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c.af[slot]), "+v"(c.bias) : "n"(ahead(S)));
+                c.acc[rt][0] = mfma16(c.af[slot], c.qf[0][0], c.bias);
+                c.acc[rt][1] = mfma16(c.af[slot], c.qf[0][1], c.bias);
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(c.af[slot]) : "n"(ahead(S)));
+                c.acc[rt][0] = mfma16(c.af[slot], c.qf[ks][0], c.acc[rt][0]);
+                c.acc[rt][1] = mfma16(c.af[slot], c.qf[ks][1], c.acc[rt][1]);
+            }
+            if constexpr ((S & 7) == 3 && S / 8 < SEARCH_PIECES) stage_piece<S / 8>(c);
+            if constexpr (ks == 2) {   // the previous chain finished two steps ago: fold it in under this chain
+                if constexpr (rt == 0) { if (have_prev) fold_chain<Ctx, KS>(c, row0 - BG, SEARCH_CHAINS - 1); }
+                else fold_chain<Ctx, KS>(c, row0, rt - 1);
+            }
+            if constexpr (S == BARRIER_STEP) {
+                // tile barrier, just before the first read of the next tile: this wave's pieces of the
+                // next tile (issued one tile ago) have landed once only this tile's pieces remain
+                if (c.do_stage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES_BEFORE_BARRIER));
+                else asm volatile("s_waitcnt vmcnt(0)");
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            SearchSteps<T, KS, NB, S + 1>::run(c, row0, have_prev);
+        }
+    }
+};
+
 template <typename T, int KS>
 __global__ __launch_bounds__(512) void search_kernel(const T* __restrict__ G, const float* __restrict__ negh,
                                                      const T* __restrict__ Qh, const float* __restrict__ qn,
@@ -122,13 +257,14 @@ __global__ __launch_bounds__(512) void search_kernel(const T* __restrict__ G, co
                                                      int tiles_total, int tiles_per_split, int QT, int S, int Qpad,
                                                      int index_base) {
     typedef typename vec8<T>::type V8;
-    constexpr int D = SEARCH_D, CH = D / 8, KSTEPS = D / 16;
-    constexpr int TILE_BYTES = BG * D * 2;          // 65536
-    constexpr int BUF_BYTES = TILE_BYTES + BG * 4;  // + bias terms
+    constexpr int D = SEARCH_D, CH = D / 8;
+    constexpr int NB = KS > 5 ? 6 : 8;   // the longer top-k lists leave room for fewer fragment slots
+    typedef SearchCtx<T, KS, NB> Ctx;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, kg = lane >> 4;
 
     // block -> (query tile, gallery split); blocks that share blockIdx % 8 share an XCD's L2, so
     // let them walk the same gallery range with different query tiles
@@ -142,87 +278,96 @@ __global__ __launch_bounds__(512) void search_kernel(const T* __restrict__ G, co
     int t_end = t_begin + tiles_per_split;
     if (t_end > tiles_total) t_end = tiles_total;
 
-    // query fragments (MFMA B operand): lane (r, h) holds Q[q][16 s + 8 h .. +8]
-    const int qrow = qt * BQ + wave * 32 + r;
-    V8 qf[KSTEPS];
+    Ctx c;
+    c.kg = kg;
+    c.wave = wave;
+    // query fragments (MFMA B operand): lane (col, kg) holds Q[q][32 s + 8 kg .. +8] of query col of tile u
+    const int qrow0 = qt * BQ + wave * 32 + col;
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) qf[s] = *reinterpret_cast<const V8*>(Qh + (size_t)qrow * D + s * 16 + h * 8);
+    for (int s = 0; s < SEARCH_KSTEPS; ++s)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            c.qf[s][u] = *reinterpret_cast<const V8*>(Qh + (size_t)(qrow0 + 16 * u) * D + s * 32 + kg * 8);
+    c.top[0].init();
+    c.top[1].init();
 
-    TopList<KS> top;
-    top.init();
+    // A fragment of step (rt, ks): row 16 rt + col, chunk 4 ks + kg  ->  lane part lo[ks & 3] plus the
+    // compile-time part 256 (ks >> 2) + 16384 rt
+    const int lds0 = (int)(unsigned)(size_t)(LPTR)smem;
+    int lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lo[j] = col * (CH * 16) + (((4 * j + kg) ^ col) << 4);
 
-    // stage one tile: 64 rows x 64 chunks; wave w stages rows w, w+8, ...; one row per instruction
-    auto stage = [&](int tile, int bufsel) {
-        char* base = smem + bufsel * BUF_BYTES;
+    // staging: piece p of a tile is row 8 p + wave, and lane l fetches the chunk that belongs at
+    // position l of that row: l ^ (row & 15) = l ^ wave for even p, (l ^ wave) ^ 8 for odd p
+    const int ch_even = lane ^ wave, ch_odd = ch_even ^ 8;
+    auto stage_all = [&](int tile, int bufsel) {
+        char* base = smem + bufsel * SEARCH_BUF_BYTES;
         const T* gt = G + (size_t)tile * BG * D;
 #pragma unroll
-        for (int i = 0; i < BG / 8; ++i) {
+        for (int i = 0; i < SEARCH_PIECES; ++i) {
             const int row = i * 8 + wave;
-            const int c = lane ^ (row & 15);
-            __builtin_amdgcn_global_load_lds((GPTR)(gt + (size_t)row * D + c * 8), (LPTR)(base + row * (CH * 16)), 16, 0,
-                                             0);
+            __builtin_amdgcn_global_load_lds((GPTR)(gt + (size_t)row * D + ((i & 1) ? ch_odd : ch_even) * 8),
+                                             (LPTR)(base + row * (CH * 16)), 16, 0, 0);
         }
-        if (wave == 0)
-            __builtin_amdgcn_global_load_lds((GPTR)(negh + (size_t)tile * BG + lane), (LPTR)(base + TILE_BYTES), 4, 0, 0);
+        if (wave == 0)   // lanes past the tile's rows re-read row 0 into the padding of the bias area
+            __builtin_amdgcn_global_load_lds((GPTR)(negh + (size_t)tile * BG + (lane < BG ? lane : 0)),
+                                             (LPTR)(base + SEARCH_TILE_BYTES), 4, 0, 0);
     };
 
-    if (t_begin < t_end) stage(t_begin, 0);
-    __syncthreads();
+    if (t_begin < t_end) {
+        stage_all(t_begin, 0);
+        if (t_begin + 1 < t_end) stage_all(t_begin + 1, 1);
+    }
+    __syncthreads();   // drains the loads above
 
-    for (int t = t_begin; t < t_end; ++t) {
-        const int cur = (t - t_begin) & 1;
-        if (t + 1 < t_end) stage(t + 1, cur ^ 1);
-        const char* base = smem + cur * BUF_BYTES;
-        const float* nh = reinterpret_cast<const float*>(base + TILE_BYTES);
-
-        f32x16 acc[2];
+    if (t_begin < t_end) {
+        int cur = 0;   // buffer of tile t; t + 1 sits in cur + 1, t + 2 is staged into cur + 2 (mod 3)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int j = 0; j < 4; ++j) c.bl[j] = lo[j] + lds0;
+        c.nha = lds0 + SEARCH_TILE_BYTES + 16 * kg;
+        __builtin_amdgcn_sched_barrier(0);
+        SearchSteps<T, KS, NB, 0>::prologue(c);
+        for (int t = t_begin; t < t_end; ++t) {
+            const int nxt = cur == 2 ? 0 : cur + 1, nn = nxt == 2 ? 0 : nxt + 1;
+            // the reads that run ahead into the next tile are issued for the last tile as well (from
+            // this tile's buffer, results unused) so that the counted waits stay exact
+            const int rb = (t + 1 < t_end ? nxt : cur) * SEARCH_BUF_BYTES + lds0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(nh + mt * 32 + 8 * q + 4 * h);
+            for (int j = 0; j < 4; ++j) c.bn[j] = lo[j] + rb;
+            c.nhn = rb + SEARCH_TILE_BYTES + 16 * kg;
+            c.do_stage = t + 2 < t_end;
+            c.ldst = smem + nn * SEARCH_BUF_BYTES + wave * (CH * 16);
+            c.nsrc = negh + (size_t)(t + 2) * BG + (lane < BG ? lane : 0);
+            c.gsrc = G + (size_t)(t + 2) * BG * D + (size_t)wave * D + ch_even * 8;
+            c.gsrc_odd = G + (size_t)(t + 2) * BG * D + (size_t)wave * D + ch_odd * 8;
+            __builtin_amdgcn_sched_barrier(0);
+            SearchSteps<T, KS, NB, 0>::run(c, t * BG, t > t_begin);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[mt][4 * q + i] = b4[i];
-            }
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            const int c = 2 * s + h;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int row = mt * 32 + r;
-                const V8 a = *reinterpret_cast<const V8*>(base + ((row * CH + (c ^ (row & 15))) << 4));
-                acc[mt] = mfma32(a, qf[s], acc[mt]);
-            }
+            for (int j = 0; j < 4; ++j) c.bl[j] = c.bn[j];
+            c.nha = c.nhn;
+            cur = nxt;
         }
-        // top-k update: cheap reject first (max of the 32 new scores against the lane's k-th best)
-        float mx = acc[0][0];
+        // retire the reads issued ahead for a tile that does not exist before their registers are reused
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c.bias));
 #pragma unroll
-        for (int g = 1; g < 16; ++g) mx = fmaxf(mx, acc[0][g]);
-#pragma unroll
-        for (int g = 0; g < 16; ++g) mx = fmaxf(mx, acc[1][g]);
-        if (__any(mx > top.s[KS - 1])) {
-            const int row0 = t * BG;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const float v = acc[mt][g];
-                    if (__any(v > top.s[KS - 1])) {
-                        if (v > top.s[KS - 1]) top.insert(v, row0 + mt * 32 + acc_row(g, h));
-                    }
-                }
-        }
-        __syncthreads();  // next tile landed (the compiler drains the LDS-DMA here); this buffer is free
+        for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(c.af[i]));
+        fold_chain<Ctx, KS>(c, (t_end - 1) * BG, SEARCH_CHAINS - 1);
     }
 
-    // partial lists: [P = 2 S][Qpad][KS], list p = 2 split + h
-    const float q2 = qn[qrow];
-    const size_t o = ((size_t)(2 * split + h) * Qpad + qrow) * KS;
+    // partial lists: [P = 4 S][Qpad][KS], list p = 4 split + kg
 #pragma unroll
-    for (int j = 0; j < KS; ++j) {
-        const bool ok = top.id[j] >= 0;
-        pdist[o + j] = ok ? fmaxf(q2 - 2.0f * top.s[j], 0.0f) : INFINITY;
-        pidx[o + j] = ok ? top.id[j] + index_base : -1;
+    for (int u = 0; u < 2; ++u) {
+        const int qrow = qrow0 + 16 * u;
+        const float q2 = qn[qrow];
+        const size_t o = ((size_t)(4 * split + kg) * Qpad + qrow) * KS;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const bool ok = c.top[u].id[j] >= 0;
+            pdist[o + j] = ok ? fmaxf(q2 - 2.0f * c.top[u].s[j], 0.0f) : INFINITY;
+            pidx[o + j] = ok ? c.top[u].id[j] + index_base : -1;
+        }
     }
 }
 
@@ -387,14 +532,14 @@ static int search_packed(fb_handle* h, const float* queries, int Q, int k, float
     const int QT = (Q + BQ - 1) / BQ, Qpad = QT * BQ;
     const int tiles = (int)(h->Npad / BG);
     const int KS = k == 1 ? 1 : (k <= 5 ? 5 : 8);
-    // splits: enough blocks to fill the chip a few times over, at most 64 (=> 128 lists per query)
+    // splits: enough blocks to fill the chip a few times over, at most 64 (=> 256 lists per query)
     int S = (1024 + QT - 1) / QT;
     if (S > 64) S = 64;
     if (S > tiles) S = tiles;
     if (S >= 8) S &= ~7;  // multiple of 8 enables the XCD-aware block mapping
     const int tps = (tiles + S - 1) / S;
     S = (tiles + tps - 1) / tps;  // drop empty splits
-    const int P = 2 * S;
+    const int P = 4 * S;   // four partial lists (lane groups) per split
 
     size_t off_qh = 0, off_qn = align_up(off_qh + (size_t)Qpad * D * 2, 256),
            off_pd = align_up(off_qn + (size_t)Qpad * 4, 256),
@@ -410,7 +555,7 @@ static int search_packed(fb_handle* h, const float* queries, int Q, int k, float
 
     hipLaunchKernelGGL(prep_queries_kernel<T>, dim3((Qpad + 3) / 4), dim3(256), 0, s, queries, qh, qn, Q, Qpad, D);
     FRA_HIP(hipGetLastError());
-    const size_t lds = 2 * (size_t)(BG * SEARCH_D * 2 + BG * 4);
+    const size_t lds = 3 * (size_t)SEARCH_BUF_BYTES;
     const dim3 grid((unsigned)(QT * S)), block(512);
     const T* G = static_cast<const T*>(h->rows);
 #define FRA_LAUNCH_SEARCH(KSV)                                                                                   \
@@ -516,7 +661,7 @@ int fb_reserve(fb_handle* h, int max_queries) {
     FRA_HIP(hipSetDevice(h->device));
     if (h->store == FRA_F32) return ensure_scratch(h, align_up((size_t)max_queries * h->N * 4, 256));
     const int QT = (max_queries + BQ - 1) / BQ, Qpad = QT * BQ;
-    const size_t P = 128, KS = 8;   // upper bounds of the partial-list layout in search_packed
+    const size_t P = 256, KS = 8;   // upper bounds of the partial-list layout in search_packed
     return ensure_scratch(h, align_up((size_t)Qpad * h->D * 2, 256) + align_up((size_t)Qpad * 4, 256) +
                                  2 * align_up(P * Qpad * KS * 4, 256));
 }

@@ -4,7 +4,7 @@ tag=$1; ctrs=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 180 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_$tag" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-search --no-cpu --no-latency "$@" > "$R/gpurun_out/pmc_$tag.log" 2>&1 || { echo "rocprof pmc failed"; tail -20 "$R/gpurun_out/pmc_$tag.log"; exit 1; }
+timeout -s KILL 180 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_$tag" -- python3 "$R/bench.py" ${PMC_BENCH_ARGS:---steps 2 --warmup 1 --no-search --no-cpu --no-latency} "$@" > "$R/gpurun_out/pmc_$tag.log" 2>&1 || { echo "rocprof pmc failed"; tail -20 "$R/gpurun_out/pmc_$tag.log"; exit 1; }
 python3 - "$R/gpurun_out/pmc_$tag" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
