@@ -2,8 +2,9 @@
 // 1x1 project (+ shortcut), one kernel, the expanded tensor never leaves the CU.
 // (reference: Depth_Wise.forward, face_model.py:55-65)
 //
-// A workgroup owns a band of TR output rows of one image.  Per 64-channel slice of the expanded
-// tensor it
+// A workgroup owns a band of TR output rows of one image; every wave owns one 32-pixel tile of the
+// band's input (expand side) and one of its output (depthwise / project side).  Per 64-channel
+// slice of the expanded tensor the workgroup
 //   1. runs the expand GEMM on the matrix cores for every input pixel of the band (+ halo rows),
 //      with the input tile's MFMA fragments held in registers for the whole kernel,
 //   2. writes PReLU(expand) as 16-bit values into an LDS image [row][x+1][64 ch] whose border
@@ -11,10 +12,22 @@
 //   3. lets every lane build, for ITS output pixel, the 3x3 depthwise result of 8 channels from
 //      nine 16-byte LDS reads, and feeds those 8 values straight to the project MFMA as its B
 //      fragment -- the depthwise output never exists in memory at all.
-// Project accumulators live in registers across slices; the epilogue adds the shortcut and stores
-// NHWC.  All parameters are read from LDS: the per-channel ones (biases, slopes, 3x3 weights) are
-// staged once, the two weight-matrix slices of the next 64 channels are fetched into registers
-// while the current slice computes and written to LDS behind a barrier.
+// Project accumulators live in registers across slices.  The epilogue turns them into rows of
+// pixels through LDS so that the shortcut is read and the result written with contiguous 8-byte
+// pieces per lane.  The weight-matrix slices of the next 64 channels are fetched into registers
+// while the current slice computes and stored into the other of two LDS buffers.
+//
+// LDS layout.  Every tile that is read as MFMA fragments or by the depthwise stage has rows of
+// 16-byte units with one unit of padding (a pixel slot of the image is 128 + 16 bytes, a weight row
+// CIN*2 + 16 or 128 + 16 bytes): 16 lanes that read the same unit of 16 consecutive rows then hit
+// 16 different 16-byte columns of the 256-byte bank window, and every unit / k-step / tap offset
+// is a compile-time constant that goes into the instruction's offset field.
+//
+// The LDS reads of both stages are issued by hand ahead of their use, with counted waits: LDS
+// returns data in order, so "at most n reads outstanding" (s_waitcnt lgkmcnt(n)) says exactly
+// which read has arrived.  A wait that allows fewer outstanding reads than necessary is always
+// safe; one that allows more is a bug -- the counts below are derived from the issue order stated
+// next to them.
 //
 // Channel order inside the expanded tensor: a lane of half h of the expand MFMA ends up with
 // channels 8q+4h+i (q<4, i<4) of each 32-channel tile, and the project MFMA wants, for k-step s,
@@ -24,22 +37,171 @@
 // by expanded channel on the depthwise/project side (bias, slope, 3x3 weights, project weight
 // columns) is stored pre-permuted on the host: natural channel 16g + 8a + 4h + i sits at
 // position 16g + 8h + 4a + i.  The two slope arrays hold (PReLU slope - 1): prelu(v) = v + (slope-1) min(v,0).
+#include <utility>
+
 #include "common.h"
 
 namespace fra {
 
-// chunk swizzle for an LDS tile whose rows hold CH 16-byte chunks (see kernels_gemm.hip)
-template <int CH> __device__ __forceinline__ int bswz(int row) {
-    if (CH >= 16) return row & 15;
-    return (row / (16 / CH)) & (CH - 1);
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// 16-byte unit swizzle of the activation image: unit u of pixel slot s is stored at u ^ ((s >> 1) & 7).
-// Slots are 128 bytes, so a ds_read_b128 lane group (16 lanes, 256-byte bank window) that reads
-// consecutive slots sees 8 even and 8 odd slots, each set with 8 distinct XOR keys: conflict free.
-__device__ __forceinline__ int eswz(int slot) { return (slot >> 1) & 7; }
+// 16-byte LDS read into `dst` from byte address `addr` (a VGPR) + compile-time `off`; the data is
+// valid only after a matching counted wait
+#define LDS_READ16(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
-template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW, bool DB>
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// ---- issue order of the depthwise stage (one slice = 4 k-steps s4 x 9 taps = 36 steps) ------------
+//   preamble : late header of s4 = 0 (project fragments a3[NT3], slopes s2a s2b), bias pair of
+//              s4 = 0, taps of steps 0 .. PD-1 (two reads each: image unit, 3x3 weights)
+//   step i   : taps of step i + PD; if i % 9 == 4 the bias pair of the next s4;  WAIT for step i;
+//              8 FMAs; if i % 9 == 8: PReLU, project MFMAs, then the late header of the next s4
+// dw_ahead(i) = reads issued after the taps of step i and before its wait.
+constexpr int DW_STEPS = 36, DW_PD = 3, DW_RING = DW_PD + 1;
+constexpr int dw_ahead(int step, int nt3) {
+    int n = 2 * (cmin(step + DW_PD, DW_STEPS - 1) - step);
+    for (int j = 4; j < DW_STEPS - 9; j += 9)          // bias pairs go out in steps 4, 13, 22
+        if (j <= step && j >= step - DW_PD) n += 2;
+    for (int e = 8; e < DW_STEPS - 9; e += 9)          // late headers after steps 8, 17, 26
+        if (e < step && e >= step - DW_PD) n += nt3 + 2;
+    return cmin(n, 15);
+}
+
+
+// ---- expand stage: LDS reads of one 32-channel tile nt, in issue order: bias quads bq[4], fragments
+// w1[KS1], slope quads sl[4]; the first pixel tile waits with counts, later tiles find the data there ----
+template <typename T, int KS1, int CEXP, int PW1> struct ExpStage {
+    typedef typename vec8<T>::type V8;
+    V8 w1[KS1];
+    f32x4 bq[4], sl[4];
+    int w1l;   // LDS address of this lane's W1 row (+ 16 h); + 32 nt PW1 + 32 ks
+    int pl;    // LDS address of this lane's bias quads of the slice; + 128 nt + 64 (q>>1) + 16 (q&1); slopes CEXP*4 further
+
+    template <int NTI, int I = 0> __device__ __forceinline__ void issue() {
+        if constexpr (I < 4) {
+            LDS_READ16(bq[I], pl, 128 * NTI + 64 * (I >> 1) + 16 * (I & 1));
+            issue<NTI, I + 1>();
+        } else if constexpr (I < 4 + KS1) {
+            LDS_READ16(w1[I - 4], w1l, NTI * 32 * PW1 + (I - 4) * 32);
+            issue<NTI, I + 1>();
+        } else if constexpr (I < 8 + KS1) {
+            constexpr int q = I - 4 - KS1;
+            LDS_READ16(sl[q], pl, CEXP * 4 + 128 * NTI + 64 * (q >> 1) + 16 * (q & 1));
+            issue<NTI, I + 1>();
+        }
+    }
+    // acc = bias + sum_ks w1[ks] . x[ks]
+    template <bool WAIT, int KS = 0> __device__ __forceinline__ void chain(f32x16& acc, const V8 (&x)[KS1]) {
+        if constexpr (KS == 0) {
+            // the four bias quads and fragment 0 have arrived once KS1 - 1 + 4 reads remain
+            if constexpr (WAIT)
+                asm volatile("s_waitcnt lgkmcnt(%5)"
+                             : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(w1[0]) : "n"(KS1 - 1 + 4));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[4 * q + i] = bq[q][i];
+            acc = mfma32(w1[0], x[0], acc);
+            __builtin_amdgcn_sched_barrier(0);             // keep each MFMA right behind its wait
+            chain<WAIT, 1>(acc, x);
+        } else if constexpr (KS < KS1) {
+            if constexpr (WAIT) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w1[KS]) : "n"(KS1 - 1 - KS + 4));
+            acc = mfma32(w1[KS], x[KS], acc);
+            __builtin_amdgcn_sched_barrier(0);
+            chain<WAIT, KS + 1>(acc, x);
+        } else {
+            if constexpr (WAIT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2]), "+v"(sl[3]));
+        }
+    }
+};
+
+// ---- depthwise + project stage of one slice (see the issue order above dw_ahead) ------------------
+template <typename T, int CEXP, int NT3, int PW3> struct DwStage {
+    typedef typename vec8<T>::type V8;
+    V8 er[DW_RING], wr[DW_RING];   // ring: image unit and 3x3 weights of a tap
+    V8 a3[NT3];                    // project fragments of the current k-step
+    f32x4 s2a, s2b, b2[2][2];
+    float d[8];
+    int tapb[9];   // LDS address of unit h of this lane's 9 taps; + 32 s4
+    int w2l;       // 3x3 weights of the slice for half h; + tap CEXP*2 + 32 s4
+    int pb;        // depthwise bias quads of the slice for half h; + 64 s4 (+16); slopes CEXP*4 further
+    int w3l;       // this lane's W3 row (+ 16 h); + 32 n3 PW3 + 32 s4
+
+    template <int ST> __device__ __forceinline__ void issue_tap() {
+        constexpr int s4 = ST / 9, k = ST % 9;
+        LDS_READ16(er[ST % DW_RING], tapb[k], 32 * s4);
+        LDS_READ16(wr[ST % DW_RING], w2l, k * CEXP * 2 + 32 * s4);
+    }
+    template <int S4, int N3 = 0> __device__ __forceinline__ void issue_late() {
+        if constexpr (N3 < NT3) {
+            LDS_READ16(a3[N3], w3l, N3 * 32 * PW3 + 32 * S4);
+            issue_late<S4, N3 + 1>();
+        } else {
+            LDS_READ16(s2a, pb, CEXP * 4 + 64 * S4);
+            LDS_READ16(s2b, pb, CEXP * 4 + 64 * S4 + 16);
+        }
+    }
+    template <int S4> __device__ __forceinline__ void issue_bias() {
+        LDS_READ16(b2[S4 & 1][0], pb, 64 * S4);
+        LDS_READ16(b2[S4 & 1][1], pb, 64 * S4 + 16);
+    }
+    template <int ST = 0> __device__ __forceinline__ void preamble() {
+        if constexpr (ST == 0) { issue_late<0>(); issue_bias<0>(); }
+        if constexpr (ST < DW_PD) { issue_tap<ST>(); preamble<ST + 1>(); }
+    }
+    template <int N3 = 0> __device__ __forceinline__ void pin_late() {
+        if constexpr (N3 < NT3) { asm volatile("" : "+v"(a3[N3])); pin_late<N3 + 1>(); }
+        else asm volatile("" : "+v"(s2a), "+v"(s2b));
+    }
+    template <int ST = 0> __device__ __forceinline__ void run(f32x16 (&pacc)[NT3]) {
+        if constexpr (ST < DW_STEPS) {
+            constexpr int s4 = ST / 9, k = ST % 9, slot = ST % DW_RING;
+            if constexpr (ST + DW_PD < DW_STEPS) issue_tap<ST + DW_PD>();
+            if constexpr (k == 4 && s4 + 1 < 4) issue_bias<s4 + 1>();
+            if constexpr (k == 0) {
+                // the bias pair went out before this step's taps, so it has arrived with them
+                asm volatile("s_waitcnt lgkmcnt(%4)"
+                             : "+v"(er[slot]), "+v"(wr[slot]), "+v"(b2[s4 & 1][0]), "+v"(b2[s4 & 1][1])
+                             : "n"(dw_ahead(ST, NT3)));
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    d[j] = fmaf((float)er[slot][j], (float)wr[slot][j], b2[s4 & 1][j >> 2][j & 3]);
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(er[slot]), "+v"(wr[slot]) : "n"(dw_ahead(ST, NT3)));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = fmaf((float)er[slot][j], (float)wr[slot][j], d[j]);
+            }
+            if constexpr (k == 8) {
+                // the late header went out before this k-step's tap PD, so it arrived before tap 8 did
+                pin_late();
+                V8 bf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bf[j] = (T)fmaf(fminf(d[j], 0.0f), s2a[j], d[j]);               // PReLU: s2 = slope - 1
+                    bf[4 + j] = (T)fmaf(fminf(d[4 + j], 0.0f), s2b[j], d[4 + j]);
+                }
+#pragma unroll
+                for (int n3 = 0; n3 < NT3; ++n3) pacc[n3] = mfma32(a3[n3], bf, pacc[n3]);
+                if constexpr (s4 + 1 < 4) {
+                    __builtin_amdgcn_sched_barrier(0);     // the header registers are free once the MFMAs are issued
+                    issue_late<s4 + 1>();
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            run<ST + 1>(pacc);
+        }
+    }
+};
+
+template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW>
 __global__ __launch_bounds__(NW * 64, MINW)
 void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float* __restrict__ b1p,
                   const float* __restrict__ s1p, const T* __restrict__ W2p, const float* __restrict__ b2p,
@@ -55,71 +217,68 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     constexpr int ROFF = WHOLE ? 1 : 0;                    // LDS row of the first computed input row
     constexpr int PIN = RCOMP * W, POUT = TR * Wo;
     constexpr int MTI = (PIN + 31) / 32, MTO = (POUT + 31) / 32;
-    constexpr int MTIW = (MTI + NW - 1) / NW, MTOW = (MTO + NW - 1) / NW;
     constexpr int KS1 = CIN / 16, NT3 = COUT / 32, NCH = CEXP / 64;
     constexpr int PITCH = W + 2;                           // pixel slots per LDS row (zero border each side)
-    constexpr int CH1 = CIN / 8;                           // 16-byte chunks per row of the W1 slice
-    // LDS map.  DB: two activation images and two copies of each weight slice, so that the expand of
-    // slice c+1 and the depthwise/project of slice c run between the same pair of barriers.
-    constexpr int NB = DB ? 2 : 1;
-    constexpr int ES_BYTES = RIN * PITCH * 128;
-    constexpr int W1_BYTES = 64 * CIN * 2, W3_BYTES = COUT * 64 * 2;
-    constexpr int OFF_W1 = NB * ES_BYTES, OFF_W3 = OFF_W1 + NB * W1_BYTES, OFF_PAR = OFF_W3 + NB * W3_BYTES;
+    constexpr int SLOT = 144;                              // bytes per pixel slot: 64 channels + one unit of padding
+    constexpr int PW1 = CIN * 2 + 16, PW3 = 144;           // padded row pitch of the W1 / W3 slices
+    constexpr int ES_BYTES = RIN * PITCH * SLOT;
+    constexpr int W1_BYTES = 64 * PW1, W3_BYTES = COUT * PW3;
+    constexpr int OFF_W1 = ES_BYTES, OFF_W3 = OFF_W1 + 2 * W1_BYTES, OFF_PAR = OFF_W3 + 2 * W3_BYTES;
     constexpr int OFF_B1 = OFF_PAR, OFF_S1 = OFF_B1 + CEXP * 4, OFF_B2 = OFF_S1 + CEXP * 4, OFF_S2 = OFF_B2 + CEXP * 4,
                   OFF_W2 = OFF_S2 + CEXP * 4;
-    constexpr int LDS_BYTES = OFF_W2 + 9 * CEXP * 2;
-    constexpr int W1_V = W1_BYTES / 16, W3_V = W3_BYTES / 16;          // 16-byte vectors per slice
+    constexpr int MAIN_BYTES = OFF_W2 + 9 * CEXP * 2;
+    constexpr int P32 = COUT * 4 + 16;                     // epilogue staging: f32 pixel rows, padded
+    constexpr int EPI_BYTES = POUT * P32;                  // overlays the image and weight buffers
+    constexpr int LDS_BYTES = cmax(MAIN_BYTES, EPI_BYTES);
+    constexpr int CH1 = CIN / 8;
+    constexpr int W1_V = 64 * CH1, W3_V = COUT * 8;        // 16-byte vectors per slice
     constexpr int W1_PT = (W1_V + NT - 1) / NT, W3_PT = (W3_V + NT - 1) / NT;
     static_assert(CEXP % 64 == 0 && CIN % 16 == 0 && COUT % 32 == 0 && Ho % TR == 0, "shape");
+    constexpr int MTIW = (MTI + NW - 1) / NW;              // input tiles per wave (stride-2 bands have more input than output)
+    static_assert(MTO <= NW, "one output tile per wave");
     static_assert(!RESID || (S == 1 && CIN == COUT), "shortcut needs matching shapes");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(NT % (COUT / 4) == 0, "epilogue: a thread keeps one channel group");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int band = blockIdx.x, img = blockIdx.y;
     const int y0 = band * TR;                              // first output row of the band
     const int row0 = WHOLE ? 0 : ((S == 1) ? y0 - 1 : 2 * y0 - 1);   // image row of the first computed input row
 
-    // ---- weight-slice staging: global -> registers (issued early) -> swizzled LDS (behind a barrier) ----
+    // ---- weight-slice staging: global -> registers (issued a slice ahead) -> padded LDS rows ----------
     V8 wreg1[W1_PT], wreg3[W3_PT];
-    auto fetch_w1 = [&](int c) {
+    auto fetch_w = [&](int c) {
 #pragma unroll
         for (int i = 0; i < W1_PT; ++i) {
             const int v = tid + i * NT;
             if (v < W1_V) wreg1[i] = *reinterpret_cast<const V8*>(W1 + (size_t)c * 64 * CIN + (size_t)v * 8);
         }
-    };
-    auto fetch_w3 = [&](int c) {
 #pragma unroll
         for (int i = 0; i < W3_PT; ++i) {
             const int v = tid + i * NT;
             if (v < W3_V) wreg3[i] = *reinterpret_cast<const V8*>(W3p + (size_t)(v >> 3) * CEXP + c * 64 + (v & 7) * 8);
         }
     };
-    auto store_w1 = [&](int buf) {
+    auto store_w = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < W1_PT; ++i) {
             const int v = tid + i * NT;
             const int row = v / CH1, ch = v - row * CH1;
-            if (v < W1_V)
-                *reinterpret_cast<V8*>(lds + OFF_W1 + buf * W1_BYTES + ((row * CH1 + (ch ^ bswz<CH1>(row))) << 4)) = wreg1[i];
+            if (v < W1_V) *reinterpret_cast<V8*>(lds + OFF_W1 + buf * W1_BYTES + row * PW1 + ch * 16) = wreg1[i];
         }
-    };
-    auto store_w3 = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < W3_PT; ++i) {
             const int v = tid + i * NT;
-            const int row = v >> 3, ch = v & 7;
-            if (v < W3_V)
-                *reinterpret_cast<V8*>(lds + OFF_W3 + buf * W3_BYTES + ((row * 8 + (ch ^ bswz<8>(row))) << 4)) = wreg3[i];
+            if (v < W3_V) *reinterpret_cast<V8*>(lds + OFF_W3 + buf * W3_BYTES + (v >> 3) * PW3 + (v & 7) * 16) = wreg3[i];
         }
     };
-    fetch_w1(0);
-    fetch_w3(0);
+    fetch_w(0);
 
-    // zero the activation image(s) once: borders and out-of-image rows are never written afterwards
-    for (int i = tid; i < NB * ES_BYTES / 16; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // zero the activation image once: borders and out-of-image rows are never written afterwards
+    for (int i = tid; i < ES_BYTES / 16; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // per-channel parameters of all slices
     for (int i = tid; i < CEXP / 4; i += NT) {
         reinterpret_cast<f32x4*>(lds + OFF_B1)[i] = reinterpret_cast<const f32x4*>(b1p)[i];
@@ -133,228 +292,157 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     // ---- input fragments (B operand of the expand GEMM), resident for the whole kernel -------
     const T* Ximg = X + (size_t)img * H * W * CIN;
     V8 xf[MTIW][KS1];
-    int in_slot[MTIW];    // LDS pixel slot of this lane's input pixel, -1 = nothing to write
+    int in_lds[MTIW];     // LDS byte address of this lane's input pixel slot (+ 16 h), -1 = nothing to write
 #pragma unroll
     for (int t = 0; t < MTIW; ++t) {
         const int p = 32 * (wave + NW * t) + r;
         const int iy = p / W, ix = p - iy * W;
         const int gy = row0 + iy;
         const bool ok = (p < PIN) && (gy >= 0) && (gy < H);
-        in_slot[t] = ok ? (iy + ROFF) * PITCH + ix + 1 : -1;
+        in_lds[t] = ok ? ((iy + ROFF) * PITCH + ix + 1) * SLOT + 16 * h : -1;
         const T* src = Ximg + ((size_t)(ok ? gy : 0) * W + (ok ? ix : 0)) * CIN + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) xf[t][ks] = *reinterpret_cast<const V8*>(src + 16 * ks);
     }
 
-    // ---- output pixel of this lane per owned output tile ------------------------------------------
-    int tap_off[MTOW][9]; // LDS byte offset of unit 0 of each of the 9 taps of this lane's output pixel
-    int out_pix[MTOW];    // pixel index inside the image's output map, -1 = padding lane
-#pragma unroll
-    for (int t = 0; t < MTOW; ++t) {
-        const int po = 32 * (wave + NW * t) + r;
-        const bool ok = (wave + NW * t < MTO) && (po < POUT);
-        const int pc = ok ? po : 0;
+    // ---- output pixel of this lane: LDS byte address of unit h of each of its 9 taps ----------
+    int tapb[9];
+    const int po = 32 * wave + r;                          // pixel inside the band's output map
+    {
+        const int pc = po < POUT ? po : 0;
         const int oy = pc / Wo, ox = pc - oy * Wo;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int slot = (oy * S + ky) * PITCH + ox * S + kx;
-                tap_off[t][ky * 3 + kx] = slot * 128 + (eswz(slot) << 4);   // unit u lives at this ^ (u << 4)
-            }
-        out_pix[t] = ok ? (y0 + oy) * Wo + ox : -1;
+            for (int kx = 0; kx < 3; ++kx) tapb[ky * 3 + kx] = ((oy * S + ky) * PITCH + ox * S + kx) * SLOT + 16 * h;
     }
 
-    // project accumulators start at the project bias: row acc_row(g,h) of tile n3 <-> channel 32 n3 + 8q + 4h + i
-    f32x16 pacc[MTOW][NT3];
+    // project accumulators: row acc_row(g,h) of tile n3 <-> channel 32 n3 + 8q + 4h + i; the bias joins in the epilogue
+    f32x16 pacc[NT3];
 #pragma unroll
     for (int n3 = 0; n3 < NT3; ++n3)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(b3 + 32 * n3 + 8 * q + 4 * h);
-#pragma unroll
-            for (int t = 0; t < MTOW; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pacc[t][n3][4 * q + i] = b[i];
-        }
+        for (int g = 0; g < 16; ++g) pacc[n3][g] = 0.0f;
 
-    // ================= expand of slice c: E[64 ch][pixels] = PReLU(W1 . X + b1) -> LDS image eb =================
-    auto expand = [&](int c, int eb, int wb) {
-        char* const es = lds + eb * ES_BYTES;
-        const char* const w1s = lds + OFF_W1 + wb * W1_BYTES;
-#pragma unroll 1
-        for (int nt = 0; nt < 2; ++nt) {
-            V8 w1[KS1];
+    // ================= expand of slice c: E[64 ch][pixels] = PReLU(W1 . X + b1) -> LDS image =================
+    ExpStage<T, KS1, CEXP, PW1> ex;
+    auto expand_tile = [&](int t, auto waitc, int nt) {
+        // one pixel tile against the fragments of channel tile nt that `ex` holds
+        f32x16 acc;
+        ex.template chain<decltype(waitc)::value>(acc, xf[t]);
+        if (in_lds[t] >= 0) {
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) {
-                const int row = nt * 32 + r, ch = 2 * ks + h;
-                w1[ks] = *reinterpret_cast<const V8*>(w1s + ((row * CH1 + (ch ^ bswz<CH1>(row))) << 4));
-            }
-            // bias / slope of this lane's 16 channels: groups g16 = 4c + 2nt + (q>>1), position 16 g16 + 8h + 4(q&1) + i
-            f32x4 bq[4];
-            const int pos1 = 16 * (4 * c + 2 * nt) + 8 * h;   // q adds 16 (q>>1) + 4 (q&1)
+            for (int s2 = 0; s2 < 2; ++s2) {
+                V8 o;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                bq[q] = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + (pos1 + 16 * (q >> 1) + 4 * (q & 1)) * 4);
+                for (int a = 0; a < 2; ++a) {
+                    const int q = 2 * s2 + a;
 #pragma unroll
-            for (int t = 0; t < MTIW; ++t) {
-                if (wave + NW * t >= MTI) continue;       // wave-uniform
-                f32x16 acc;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[4 * q + i] = bq[q][i];
-#pragma unroll
-                for (int ks = 0; ks < KS1; ++ks) acc = mfma32(w1[ks], xf[t][ks], acc);
-                if (in_slot[t] >= 0) {
-                    char* dst = es + in_slot[t] * 128;
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        V8 o;
-#pragma unroll
-                        for (int a = 0; a < 2; ++a) {
-                            const int q = 2 * s2 + a;
-                            const f32x4 sl = *reinterpret_cast<const f32x4*>(lds + OFF_S1 + (pos1 + 16 * s2 + 4 * a) * 4);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float v = acc[4 * q + i];
-                                o[4 * a + i] = (T)fmaf(fminf(v, 0.0f), sl[i], v);   // PReLU: sl = slope - 1
-                            }
-                        }
-                        const int u = (2 * nt + s2) * 2 + h;          // 16-byte unit inside the 128-byte slot
-                        *reinterpret_cast<V8*>(dst + ((u ^ eswz(in_slot[t])) << 4)) = o;
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = acc[4 * q + i];
+                        o[4 * a + i] = (T)fmaf(fminf(v, 0.0f), ex.sl[q][i], v);   // PReLU: sl = slope - 1
                     }
                 }
+                // 16-byte unit (2 nt + s2) * 2 + h of the slot
+                *reinterpret_cast<V8*>(lds + in_lds[t] + (2 * nt + s2) * 32) = o;
             }
         }
     };
-
-    // ================= depthwise 3x3 of slice c from LDS image eb -> project MFMA =================================
-    auto dwproject = [&](int c, int eb, int wb) {
-        const char* const es = lds + eb * ES_BYTES;
-        const char* const w3s = lds + OFF_W3 + wb * W3_BYTES;
-#pragma unroll 2
-        for (int s4 = 0; s4 < 4; ++s4) {                  // 16-channel k-step of the slice
-            const int pos = c * 64 + 16 * s4 + 8 * h;     // permuted position of this half's 8 channels
-            const int u = 2 * s4 + h;
-            const char* w2base = lds + OFF_W2 + pos * 2;
-            const f32x4 b2a = *reinterpret_cast<const f32x4*>(lds + OFF_B2 + pos * 4),
-                        b2b = *reinterpret_cast<const f32x4*>(lds + OFF_B2 + pos * 4 + 16);
-            const f32x4 s2a = *reinterpret_cast<const f32x4*>(lds + OFF_S2 + pos * 4),
-                        s2b = *reinterpret_cast<const f32x4*>(lds + OFF_S2 + pos * 4 + 16);
-            V8 a3[NT3];
+    auto expand = [&](int c, int wb) {
+        if (wave >= MTI) return;                           // wave-uniform; such a wave has no later tile either
+        ex.w1l = OFF_W1 + wb * W1_BYTES + r * PW1 + 16 * h;
+        ex.pl = OFF_B1 + 256 * c + 32 * h;
+        ex.template issue<0>();
+        expand_tile(0, std::true_type{}, 0);
 #pragma unroll
-            for (int n3 = 0; n3 < NT3; ++n3) {
-                const int row = 32 * n3 + r, ch = 2 * s4 + h;
-                a3[n3] = *reinterpret_cast<const V8*>(w3s + ((row * 8 + (ch ^ bswz<8>(row))) << 4));
-            }
+        for (int t = 1; t < MTIW; ++t)
+            if (wave + NW * t < MTI) expand_tile(t, std::false_type{}, 0);
+        ex.template issue<1>();
+        expand_tile(0, std::true_type{}, 1);
 #pragma unroll
-            for (int t = 0; t < MTOW; ++t) {
-                if (wave + NW * t >= MTO) continue;       // wave-uniform
-                float d[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { d[j] = b2a[j]; d[4 + j] = b2b[j]; }
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const V8 e = *reinterpret_cast<const V8*>(es + (tap_off[t][ky * 3 + kx] ^ (u << 4)));
-                        const V8 wk = *reinterpret_cast<const V8*>(w2base + (ky * 3 + kx) * CEXP * 2);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) d[j] = fmaf((float)e[j], (float)wk[j], d[j]);
-                    }
-                V8 bf;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    bf[j] = (T)fmaf(fminf(d[j], 0.0f), s2a[j], d[j]);               // PReLU: s2 = slope - 1
-                    bf[4 + j] = (T)fmaf(fminf(d[4 + j], 0.0f), s2b[j], d[4 + j]);
-                }
-#pragma unroll
-                for (int n3 = 0; n3 < NT3; ++n3) pacc[t][n3] = mfma32(a3[n3], bf, pacc[t][n3]);
-            }
-        }
+        for (int t = 1; t < MTIW; ++t)
+            if (wave + NW * t < MTI) expand_tile(t, std::false_type{}, 1);
     };
 
-    if (!DB) {
-        // one image, one copy of the weight slices: expand | barrier | depthwise+project | barrier | restage | barrier
-        store_w1(0);
-        store_w3(0);
-        __syncthreads();
+    // ================= depthwise 3x3 of slice c from the LDS image -> project MFMA =================================
+    DwStage<T, CEXP, NT3, PW3> dw;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dw.tapb[k] = tapb[k];
+    auto dwproject = [&](int c, int wb) {
+        if (wave >= MTO) return;                           // wave-uniform
+        dw.w2l = OFF_W2 + 128 * c + 16 * h;
+        dw.pb = OFF_B2 + 256 * c + 32 * h;
+        dw.w3l = OFF_W3 + wb * W3_BYTES + r * PW3 + 16 * h;
+        dw.preamble();
+        dw.run(pacc);
+    };
+
+    // expand | barrier | depthwise+project, next slice's weights into the other buffer | barrier
+    store_w(0);
+    if (NCH > 1) fetch_w(1);
+    __syncthreads();
 #pragma unroll 1
-        for (int c = 0; c < NCH; ++c) {
-            expand(c, 0, 0);
-            if (c + 1 < NCH) { fetch_w1(c + 1); fetch_w3(c + 1); }   // in flight during the depthwise / project phase
-            __syncthreads();
-            dwproject(c, 0, 0);
-            __syncthreads();   // every wave is done with this slice's LDS image and weights
-            if (c + 1 < NCH) {
-                store_w1(0);
-                store_w3(0);
-                __syncthreads();
-            }
+    for (int c = 0; c < NCH; ++c) {
+        expand(c, c & 1);
+        __syncthreads();                       // the image of slice c is complete
+        dwproject(c, c & 1);
+        if (c + 1 < NCH) {
+            store_w((c + 1) & 1);              // that buffer was last read before the previous barrier
+            if (c + 2 < NCH) fetch_w(c + 2);
         }
-    } else {
-        // software pipeline over slices: between two barriers a wave expands slice c+1 into one image and runs
-        // depthwise+project of slice c from the other.  W1 of slice c sits in buffer c&1, W3 likewise.
-        store_w1(0);
-        store_w3(0);
-        if (NCH > 1) fetch_w1(1);
-        __syncthreads();
-        expand(0, 0, 0);
-        if (NCH > 1) store_w1(1);
-        __syncthreads();
-#pragma unroll 1
-        for (int c = 0; c < NCH; ++c) {
-            if (c + 2 < NCH) fetch_w1(c + 2);
-            if (c + 1 < NCH) fetch_w3(c + 1);
-            if (c + 1 < NCH) expand(c + 1, (c + 1) & 1, (c + 1) & 1);
-            dwproject(c, c & 1, c & 1);
-            // W1 buffer c&1 held slice c (last read before the previous barrier); W3 buffer (c+1)&1 held slice c-1
-            if (c + 2 < NCH) store_w1(c & 1);
-            if (c + 1 < NCH) store_w3((c + 1) & 1);
-            __syncthreads();
-        }
+        __syncthreads();                       // image and old weights free, new weights visible
     }
 
-    // ---- epilogue: (+ shortcut) -> NHWC store, 4 channels = 8 bytes per lane per register quad -------
-    T* Oimg = O + (size_t)img * Ho * Wo * COUT;
-#pragma unroll
-    for (int t = 0; t < MTOW; ++t) {
-        if (out_pix[t] < 0) continue;
+    // ---- epilogue: accumulators -> f32 pixel rows in LDS -> (+ bias, + shortcut) -> NHWC, 8 bytes per lane -------
+    if (wave < MTO && po < POUT) {
+        char* dst = lds + po * P32 + 16 * h;
 #pragma unroll
         for (int n3 = 0; n3 < NT3; ++n3)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = 32 * n3 + 8 * q + 4 * h;
-                float v[4];
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(dst + (32 * n3 + 8 * q) * 4) =
+                    f32x4{pacc[n3][4 * q], pacc[n3][4 * q + 1], pacc[n3][4 * q + 2], pacc[n3][4 * q + 3]};
+    }
+    __syncthreads();
+    {
+        constexpr int G = COUT / 4, UNITS = POUT * G;      // a unit = 4 channels of one pixel
+        const int g = tid % G;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(b3 + 4 * g);
+        const size_t pix0 = (size_t)img * Ho * Wo + (size_t)y0 * Wo;
+        const T* Xo = X + pix0 * CIN;
+        T* Oo = O + pix0 * COUT;
+#pragma unroll 4
+        for (int u = tid; u < UNITS; u += NT) {
+            const int p = u / G;
+            f32x4 v = *reinterpret_cast<const f32x4*>(lds + p * P32 + g * 16);
+            if (RESID) {
+                const V4 rr = *reinterpret_cast<const V4*>(Xo + (size_t)p * CIN + 4 * g);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = pacc[t][n3][4 * q + i];
-                if (RESID) {
-                    const V4 rr = *reinterpret_cast<const V4*>(Ximg + (size_t)out_pix[t] * CIN + n);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)rr[i];
-                }
-                V4 o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (T)v[i];
-                *reinterpret_cast<V4*>(Oimg + (size_t)out_pix[t] * COUT + n) = o;
+                for (int i = 0; i < 4; ++i) v[i] += (float)rr[i];
             }
+            V4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (T)(v[i] + bias[i]);
+            *reinterpret_cast<V4*>(Oo + (size_t)p * COUT + 4 * g) = o;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int CEXP, int COUT, int H, int S, int TR, bool DB>
+template <int CIN, int CEXP, int COUT, int H, int S, int TR>
 constexpr int block_lds_bytes() {
     constexpr int RIN = (S == 1) ? TR + 2 : 2 * TR + 1;
-    return (DB ? 2 : 1) * (RIN * (H + 2) * 128 + 64 * CIN * 2 + COUT * 64 * 2) + 4 * CEXP * 4 + 9 * CEXP * 2;
+    constexpr int main_bytes = RIN * (H + 2) * 144 + 2 * 64 * (CIN * 2 + 16) + 2 * COUT * 144 + 4 * CEXP * 4 + 9 * CEXP * 2;
+    constexpr int epi_bytes = TR * (H / S) * (COUT * 4 + 16);
+    return cmax(main_bytes, epi_bytes);
 }
 
-template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW, bool DB>
+template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW>
 static int launch_block_cfg(const BlockParams& p, const void* x, void* out, int B, hipStream_t s) {
     FRA_REQUIRE(p.cout == COUT, FRA_ERR_ARG, "block: cout %d, fused kernel has %d", p.cout, COUT);
     const dim3 grid((H / S) / TR, B), block(NW * 64);
-    constexpr int lds = block_lds_bytes<CIN, CEXP, COUT, H, S, TR, DB>();
-    auto kern = block_kernel<T, CIN, CEXP, COUT, H, S, TR, RESID, NW, MINW, DB>;
+    constexpr int lds = block_lds_bytes<CIN, CEXP, COUT, H, S, TR>();
+    auto kern = block_kernel<T, CIN, CEXP, COUT, H, S, TR, RESID, NW, MINW>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         FRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -371,17 +459,17 @@ static int launch_block_t(const BlockParams& p, const void* x, void* out, int B,
     const int key = p.cin * 1000000 + p.cexp * 1000 + p.h * 10 + p.stride;
     switch (key) {
         case 64 * 1000000 + 128 * 1000 + 56 * 10 + 2:   // conv_23
-            return launch_block_cfg<T, 64, 128, 64, 56, 2, 4, false, 8, 2, false>(p, x, out, B, s);
+            return launch_block_cfg<T, 64, 128, 64, 56, 2, 4, false, 8, 2>(p, x, out, B, s);
         case 64 * 1000000 + 128 * 1000 + 28 * 10 + 1:   // conv_3.*
-            return launch_block_cfg<T, 64, 128, 64, 28, 1, 7, true, 8, 4, false>(p, x, out, B, s);
+            return launch_block_cfg<T, 64, 128, 64, 28, 1, 7, true, 8, 2>(p, x, out, B, s);
         case 64 * 1000000 + 256 * 1000 + 28 * 10 + 2:   // conv_34
-            return launch_block_cfg<T, 64, 256, 128, 28, 2, 7, false, 8, 2, false>(p, x, out, B, s);
+            return launch_block_cfg<T, 64, 256, 128, 28, 2, 7, false, 8, 2>(p, x, out, B, s);
         case 128 * 1000000 + 256 * 1000 + 14 * 10 + 1:  // conv_4.*
-            return launch_block_cfg<T, 128, 256, 128, 14, 1, 14, true, 8, 2, true>(p, x, out, B, s);
+            return launch_block_cfg<T, 128, 256, 128, 14, 1, 14, true, 8, 2>(p, x, out, B, s);
         case 128 * 1000000 + 512 * 1000 + 14 * 10 + 2:  // conv_45
-            return launch_block_cfg<T, 128, 512, 128, 14, 2, 7, false, 8, 2, true>(p, x, out, B, s);
+            return launch_block_cfg<T, 128, 512, 128, 14, 2, 7, false, 8, 2>(p, x, out, B, s);
         case 128 * 1000000 + 256 * 1000 + 7 * 10 + 1:   // conv_5.*
-            return launch_block_cfg<T, 128, 256, 128, 7, 1, 7, true, 8, 2, true>(p, x, out, B, s);
+            return launch_block_cfg<T, 128, 256, 128, 7, 1, 7, true, 8, 2>(p, x, out, B, s);
         default: break;
     }
     FRA_REQUIRE(false, FRA_ERR_ARG, "block: no fused kernel for cin=%d cexp=%d h=%d stride=%d", p.cin, p.cexp, p.h,
