@@ -201,7 +201,7 @@ template <typename T, int CEXP, int NT3, int PW3> struct DwStage {
     }
 };
 
-template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW>
+template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW, int MODE>
 __global__ __launch_bounds__(NW * 64, MINW)
 void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float* __restrict__ b1p,
                   const float* __restrict__ s1p, const T* __restrict__ W2p, const float* __restrict__ b2p,
@@ -216,14 +216,20 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     constexpr int RCOMP = WHOLE ? H : RIN;                 // input rows the expand GEMM runs on
     constexpr int ROFF = WHOLE ? 1 : 0;                    // LDS row of the first computed input row
     constexpr int PIN = RCOMP * W, POUT = TR * Wo;
-    constexpr int MTI = (PIN + 31) / 32, MTO = (POUT + 31) / 32;
+    // Output tiles are row aligned: a tile holds RPT whole output rows, each padded to POW (a power of two)
+    // lanes, so that the pixel slots a 16-lane group reads are consecutive -- a tile of 32 consecutive pixels
+    // would skip the two border slots at every row end and put two lanes on one bank.
+    constexpr int POW = Wo <= 8 ? 8 : (Wo <= 16 ? 16 : 32), RPT = 32 / POW;
+    constexpr int MTI = (PIN + 31) / 32, MTO = (TR + RPT - 1) / RPT;
     constexpr int KS1 = CIN / 16, NT3 = COUT / 32, NCH = CEXP / 64;
     constexpr int PITCH = W + 2;                           // pixel slots per LDS row (zero border each side)
     constexpr int SLOT = 144;                              // bytes per pixel slot: 64 channels + one unit of padding
     constexpr int PW1 = CIN * 2 + 16, PW3 = 144;           // padded row pitch of the W1 / W3 slices
     constexpr int ES_BYTES = RIN * PITCH * SLOT;
     constexpr int W1_BYTES = 64 * PW1, W3_BYTES = COUT * PW3;
-    constexpr int OFF_W1 = ES_BYTES, OFF_W3 = OFF_W1 + 2 * W1_BYTES, OFF_PAR = OFF_W3 + 2 * W3_BYTES;
+    constexpr int NWB = MODE >= 1 ? 2 : 1;                 // LDS copies of each weight slice
+    constexpr int NEB = MODE == 2 ? 2 : 1;                 // LDS copies of the expanded image
+    constexpr int OFF_W1 = NEB * ES_BYTES, OFF_W3 = OFF_W1 + NWB * W1_BYTES, OFF_PAR = OFF_W3 + NWB * W3_BYTES;
     constexpr int OFF_B1 = OFF_PAR, OFF_S1 = OFF_B1 + CEXP * 4, OFF_B2 = OFF_S1 + CEXP * 4, OFF_S2 = OFF_B2 + CEXP * 4,
                   OFF_W2 = OFF_S2 + CEXP * 4;
     constexpr int MAIN_BYTES = OFF_W2 + 9 * CEXP * 2;
@@ -278,7 +284,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     fetch_w(0);
 
     // zero the activation image once: borders and out-of-image rows are never written afterwards
-    for (int i = tid; i < ES_BYTES / 16; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < NEB * ES_BYTES / 16; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // per-channel parameters of all slices
     for (int i = tid; i < CEXP / 4; i += NT) {
         reinterpret_cast<f32x4*>(lds + OFF_B1)[i] = reinterpret_cast<const f32x4*>(b1p)[i];
@@ -307,14 +313,15 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 
     // ---- output pixel of this lane: LDS byte address of unit h of each of its 9 taps ----------
     int tapb[9];
-    const int po = 32 * wave + r;                          // pixel inside the band's output map
+    const int oy = wave * RPT + r / POW, ox = r % POW;     // this lane's output pixel inside the band
+    const bool out_ok = (ox < Wo) && (oy < TR);
+    const int po = oy * Wo + ox;
     {
-        const int pc = po < POUT ? po : 0;
-        const int oy = pc / Wo, ox = pc - oy * Wo;
+        const int cy = out_ok ? oy : 0, cx = out_ok ? ox : 0;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) tapb[ky * 3 + kx] = ((oy * S + ky) * PITCH + ox * S + kx) * SLOT + 16 * h;
+            for (int kx = 0; kx < 3; ++kx) tapb[ky * 3 + kx] = ((cy * S + ky) * PITCH + cx * S + kx) * SLOT + 16 * h;
     }
 
     // project accumulators: row acc_row(g,h) of tile n3 <-> channel 32 n3 + 8q + 4h + i; the bias joins in the epilogue
@@ -325,8 +332,8 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         for (int g = 0; g < 16; ++g) pacc[n3][g] = 0.0f;
 
     // ================= expand of slice c: E[64 ch][pixels] = PReLU(W1 . X + b1) -> LDS image =================
-    ExpStage<T, KS1, CEXP, PW1> ex;
-    auto expand_tile = [&](int t, auto waitc, int nt) {
+    typedef ExpStage<T, KS1, CEXP, PW1> Ex;
+    auto expand_tile = [&](Ex& ex, int t, auto waitc, int nt, int eoff) {
         // one pixel tile against the fragments of channel tile nt that `ex` holds
         f32x16 acc;
         ex.template chain<decltype(waitc)::value>(acc, xf[t]);
@@ -344,32 +351,34 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
                     }
                 }
                 // 16-byte unit (2 nt + s2) * 2 + h of the slot
-                *reinterpret_cast<V8*>(lds + in_lds[t] + (2 * nt + s2) * 32) = o;
+                *reinterpret_cast<V8*>(lds + eoff + in_lds[t] + (2 * nt + s2) * 32) = o;
             }
         }
     };
-    auto expand = [&](int c, int wb) {
+    auto expand = [&](int c, int wb, int eb) {
         if (wave >= MTI) return;                           // wave-uniform; such a wave has no later tile either
+        const int eoff = eb * ES_BYTES;
+        Ex ex;   // lives only inside this call, so its registers are free for the other stage
         ex.w1l = OFF_W1 + wb * W1_BYTES + r * PW1 + 16 * h;
         ex.pl = OFF_B1 + 256 * c + 32 * h;
         ex.template issue<0>();
-        expand_tile(0, std::true_type{}, 0);
+        expand_tile(ex, 0, std::true_type{}, 0, eoff);
 #pragma unroll
         for (int t = 1; t < MTIW; ++t)
-            if (wave + NW * t < MTI) expand_tile(t, std::false_type{}, 0);
+            if (wave + NW * t < MTI) expand_tile(ex, t, std::false_type{}, 0, eoff);
         ex.template issue<1>();
-        expand_tile(0, std::true_type{}, 1);
+        expand_tile(ex, 0, std::true_type{}, 1, eoff);
 #pragma unroll
         for (int t = 1; t < MTIW; ++t)
-            if (wave + NW * t < MTI) expand_tile(t, std::false_type{}, 1);
+            if (wave + NW * t < MTI) expand_tile(ex, t, std::false_type{}, 1, eoff);
     };
 
     // ================= depthwise 3x3 of slice c from the LDS image -> project MFMA =================================
-    DwStage<T, CEXP, NT3, PW3> dw;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) dw.tapb[k] = tapb[k];
-    auto dwproject = [&](int c, int wb) {
+    auto dwproject = [&](int c, int wb, int eb) {
         if (wave >= MTO) return;                           // wave-uniform
+        DwStage<T, CEXP, NT3, PW3> dw;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dw.tapb[k] = tapb[k] + eb * ES_BYTES;
         dw.w2l = OFF_W2 + 128 * c + 16 * h;
         dw.pb = OFF_B2 + 256 * c + 32 * h;
         dw.w3l = OFF_W3 + wb * W3_BYTES + r * PW3 + 16 * h;
@@ -377,24 +386,100 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         dw.run(pacc);
     };
 
-    // expand | barrier | depthwise+project, next slice's weights into the other buffer | barrier
-    store_w(0);
-    if (NCH > 1) fetch_w(1);
-    __syncthreads();
+    if (MODE == 2) {
+        // Two images, two copies of the weight slices.  Between two barriers a wave expands slice c+1 into one
+        // image and runs depthwise+project of slice c from the other; the two waves that share a SIMD
+        // (w and w + NW/2) take the two phases in opposite order, so one's matrix-core phase runs under
+        // the other's vector phase.  W1 of slice c sits in buffer c&1, W3 likewise.
+        auto fetch_w1 = [&](int c) {
+#pragma unroll
+            for (int i = 0; i < W1_PT; ++i) {
+                const int v = tid + i * NT;
+                if (v < W1_V) wreg1[i] = *reinterpret_cast<const V8*>(W1 + (size_t)c * 64 * CIN + (size_t)v * 8);
+            }
+        };
+        auto fetch_w3 = [&](int c) {
+#pragma unroll
+            for (int i = 0; i < W3_PT; ++i) {
+                const int v = tid + i * NT;
+                if (v < W3_V) wreg3[i] = *reinterpret_cast<const V8*>(W3p + (size_t)(v >> 3) * CEXP + c * 64 + (v & 7) * 8);
+            }
+        };
+        auto store_w1 = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < W1_PT; ++i) {
+                const int v = tid + i * NT;
+                const int row = v / CH1, ch = v - row * CH1;
+                if (v < W1_V) *reinterpret_cast<V8*>(lds + OFF_W1 + buf * W1_BYTES + row * PW1 + ch * 16) = wreg1[i];
+            }
+        };
+        auto store_w3 = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < W3_PT; ++i) {
+                const int v = tid + i * NT;
+                if (v < W3_V) *reinterpret_cast<V8*>(lds + OFF_W3 + buf * W3_BYTES + (v >> 3) * PW3 + (v & 7) * 16) = wreg3[i];
+            }
+        };
+        const bool expand_first = (wave & (NW / 2)) == 0;
+        store_w(0);
+        if (NCH > 1) fetch_w1(1);
+        __syncthreads();
+        expand(0, 0, 0);
+        if (NCH > 1) { store_w1(1); fetch_w3(1); }
+        if (NCH > 2) fetch_w1(2);
+        __syncthreads();
 #pragma unroll 1
-    for (int c = 0; c < NCH; ++c) {
-        expand(c, c & 1);
-        __syncthreads();                       // the image of slice c is complete
-        dwproject(c, c & 1);
-        if (c + 1 < NCH) {
-            store_w((c + 1) & 1);              // that buffer was last read before the previous barrier
-            if (c + 2 < NCH) fetch_w(c + 2);
+        for (int c = 0; c < NCH; ++c) {
+            if (!expand_first) dwproject(c, c & 1, c & 1);
+            __builtin_amdgcn_sched_barrier(0);       // keep the two stages' registers from overlapping
+            if (c + 1 < NCH) expand(c + 1, (c + 1) & 1, (c + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (expand_first) dwproject(c, c & 1, c & 1);
+            // W1 buffer c&1 held slice c (last read before the previous barrier); W3 buffer (c+1)&1 held slice c-1
+            if (c + 2 < NCH) store_w1(c & 1);
+            if (c + 1 < NCH) store_w3((c + 1) & 1);
+            if (c + 3 < NCH) fetch_w1(c + 3);
+            if (c + 2 < NCH) fetch_w3(c + 2);
+            __syncthreads();
         }
-        __syncthreads();                       // image and old weights free, new weights visible
+    } else if (MODE == 1) {
+        // expand | barrier | depthwise+project, next slice's weights into the other buffer | barrier
+        store_w(0);
+        if (NCH > 1) fetch_w(1);
+        __syncthreads();
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            expand(c, c & 1, 0);
+            __syncthreads();                       // the image of slice c is complete
+            dwproject(c, c & 1, 0);
+            if (c + 1 < NCH) {
+                store_w((c + 1) & 1);              // that buffer was last read before the previous barrier
+                if (c + 2 < NCH) fetch_w(c + 2);
+            }
+            __syncthreads();                       // image and old weights free, new weights visible
+        }
+    } else {
+        // one copy of the weight slices (less LDS, so that two workgroups share a CU and fill each
+        // other's barrier waits): expand | barrier | depthwise+project | barrier | restage | barrier
+        store_w(0);
+        if (NCH > 1) fetch_w(1);
+        __syncthreads();
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            expand(c, 0, 0);
+            __syncthreads();
+            dwproject(c, 0, 0);
+            __syncthreads();
+            if (c + 1 < NCH) {
+                store_w(0);
+                if (c + 2 < NCH) fetch_w(c + 2);
+                __syncthreads();
+            }
+        }
     }
 
     // ---- epilogue: accumulators -> f32 pixel rows in LDS -> (+ bias, + shortcut) -> NHWC, 8 bytes per lane -------
-    if (wave < MTO && po < POUT) {
+    if (wave < MTO && out_ok) {
         char* dst = lds + po * P32 + 16 * h;
 #pragma unroll
         for (int n3 = 0; n3 < NT3; ++n3)
@@ -429,20 +514,21 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int CEXP, int COUT, int H, int S, int TR>
+template <int CIN, int CEXP, int COUT, int H, int S, int TR, int MODE>
 constexpr int block_lds_bytes() {
     constexpr int RIN = (S == 1) ? TR + 2 : 2 * TR + 1;
-    constexpr int main_bytes = RIN * (H + 2) * 144 + 2 * 64 * (CIN * 2 + 16) + 2 * COUT * 144 + 4 * CEXP * 4 + 9 * CEXP * 2;
+    constexpr int main_bytes = (MODE == 2 ? 2 : 1) * RIN * (H + 2) * 144 +
+                               (MODE >= 1 ? 2 : 1) * (64 * (CIN * 2 + 16) + COUT * 144) + 4 * CEXP * 4 + 9 * CEXP * 2;
     constexpr int epi_bytes = TR * (H / S) * (COUT * 4 + 16);
     return cmax(main_bytes, epi_bytes);
 }
 
-template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW>
+template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW, int MODE>
 static int launch_block_cfg(const BlockParams& p, const void* x, void* out, int B, hipStream_t s) {
     FRA_REQUIRE(p.cout == COUT, FRA_ERR_ARG, "block: cout %d, fused kernel has %d", p.cout, COUT);
     const dim3 grid((H / S) / TR, B), block(NW * 64);
-    constexpr int lds = block_lds_bytes<CIN, CEXP, COUT, H, S, TR>();
-    auto kern = block_kernel<T, CIN, CEXP, COUT, H, S, TR, RESID, NW, MINW>;
+    constexpr int lds = block_lds_bytes<CIN, CEXP, COUT, H, S, TR, MODE>();
+    auto kern = block_kernel<T, CIN, CEXP, COUT, H, S, TR, RESID, NW, MINW, MODE>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         FRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -459,17 +545,17 @@ static int launch_block_t(const BlockParams& p, const void* x, void* out, int B,
     const int key = p.cin * 1000000 + p.cexp * 1000 + p.h * 10 + p.stride;
     switch (key) {
         case 64 * 1000000 + 128 * 1000 + 56 * 10 + 2:   // conv_23
-            return launch_block_cfg<T, 64, 128, 64, 56, 2, 4, false, 8, 2>(p, x, out, B, s);
+            return launch_block_cfg<T, 64, 128, 64, 56, 2, 4, false, 8, 2, 1>(p, x, out, B, s);
         case 64 * 1000000 + 128 * 1000 + 28 * 10 + 1:   // conv_3.*
-            return launch_block_cfg<T, 64, 128, 64, 28, 1, 7, true, 8, 2>(p, x, out, B, s);
+            return launch_block_cfg<T, 64, 128, 64, 28, 1, 4, true, 4, 2, 1>(p, x, out, B, s);
         case 64 * 1000000 + 256 * 1000 + 28 * 10 + 2:   // conv_34
-            return launch_block_cfg<T, 64, 256, 128, 28, 2, 7, false, 8, 2>(p, x, out, B, s);
+            return launch_block_cfg<T, 64, 256, 128, 28, 2, 7, false, 8, 2, 1>(p, x, out, B, s);
         case 128 * 1000000 + 256 * 1000 + 14 * 10 + 1:  // conv_4.*
-            return launch_block_cfg<T, 128, 256, 128, 14, 1, 14, true, 8, 2>(p, x, out, B, s);
+            return launch_block_cfg<T, 128, 256, 128, 14, 1, 14, true, 8, 2, 1>(p, x, out, B, s);
         case 128 * 1000000 + 512 * 1000 + 14 * 10 + 2:  // conv_45
-            return launch_block_cfg<T, 128, 512, 128, 14, 2, 7, false, 8, 2>(p, x, out, B, s);
+            return launch_block_cfg<T, 128, 512, 128, 14, 2, 7, false, 8, 2, 1>(p, x, out, B, s);
         case 128 * 1000000 + 256 * 1000 + 7 * 10 + 1:   // conv_5.*
-            return launch_block_cfg<T, 128, 256, 128, 7, 1, 7, true, 8, 2>(p, x, out, B, s);
+            return launch_block_cfg<T, 128, 256, 128, 7, 1, 7, true, 8, 2, 1>(p, x, out, B, s);
         default: break;
     }
     FRA_REQUIRE(false, FRA_ERR_ARG, "block: no fused kernel for cin=%d cexp=%d h=%d stride=%d", p.cin, p.cexp, p.h,
