@@ -206,7 +206,7 @@ __global__ __launch_bounds__(NW * 64, MINW)
 void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float* __restrict__ b1p,
                   const float* __restrict__ s1p, const T* __restrict__ W2p, const float* __restrict__ b2p,
                   const float* __restrict__ s2p, const T* __restrict__ W3p, const float* __restrict__ b3,
-                  T* __restrict__ O) {
+                  T* __restrict__ O, int B) {
     typedef typename vec8<T>::type V8;
     typedef typename vec4<T>::type V4;
     constexpr int NT = NW * 64;
@@ -228,8 +228,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     constexpr int ES_BYTES = RIN * PITCH * SLOT;
     constexpr int W1_BYTES = 64 * PW1, W3_BYTES = COUT * PW3;
     constexpr int NWB = MODE >= 1 ? 2 : 1;                 // LDS copies of each weight slice
-    constexpr int NEB = MODE == 2 ? 2 : 1;                 // LDS copies of the expanded image
-    constexpr int OFF_W1 = NEB * ES_BYTES, OFF_W3 = OFF_W1 + NWB * W1_BYTES, OFF_PAR = OFF_W3 + NWB * W3_BYTES;
+    constexpr int OFF_W1 = ES_BYTES, OFF_W3 = OFF_W1 + NWB * W1_BYTES, OFF_PAR = OFF_W3 + NWB * W3_BYTES;
     constexpr int OFF_B1 = OFF_PAR, OFF_S1 = OFF_B1 + CEXP * 4, OFF_B2 = OFF_S1 + CEXP * 4, OFF_S2 = OFF_B2 + CEXP * 4,
                   OFF_W2 = OFF_S2 + CEXP * 4;
     constexpr int MAIN_BYTES = OFF_W2 + 9 * CEXP * 2;
@@ -245,12 +244,14 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     static_assert(!RESID || (S == 1 && CIN == COUT), "shortcut needs matching shapes");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(NT % (COUT / 4) == 0, "epilogue: a thread keeps one channel group");
+    static_assert(EPI_BYTES <= OFF_PAR, "the epilogue staging must not reach the per-channel parameters");
+    static_assert(NCH >= 2, "the weight pipeline below assumes at least two slices");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int band = blockIdx.x, img = blockIdx.y;
+    const int band = blockIdx.x;
     const int y0 = band * TR;                              // first output row of the band
     const int row0 = WHOLE ? 0 : ((S == 1) ? y0 - 1 : 2 * y0 - 1);   // image row of the first computed input row
 
@@ -283,8 +284,6 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     };
     fetch_w(0);
 
-    // zero the activation image once: borders and out-of-image rows are never written afterwards
-    for (int i = tid; i < NEB * ES_BYTES / 16; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // per-channel parameters of all slices
     for (int i = tid; i < CEXP / 4; i += NT) {
         reinterpret_cast<f32x4*>(lds + OFF_B1)[i] = reinterpret_cast<const f32x4*>(b1p)[i];
@@ -295,10 +294,10 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     for (int i = tid; i < 9 * CEXP / 8; i += NT)
         reinterpret_cast<V8*>(lds + OFF_W2)[i] = reinterpret_cast<const V8*>(W2p)[i];
 
-    // ---- input fragments (B operand of the expand GEMM), resident for the whole kernel -------
-    const T* Ximg = X + (size_t)img * H * W * CIN;
+    // ---- input fragments (B operand of the expand GEMM), resident while an image's slices are expanded -------
     V8 xf[MTIW][KS1];
     int in_lds[MTIW];     // LDS byte address of this lane's input pixel slot (+ 16 h), -1 = nothing to write
+    int x_off[MTIW];      // element offset of this lane's input pixel inside an image (+ 8 h)
 #pragma unroll
     for (int t = 0; t < MTIW; ++t) {
         const int p = 32 * (wave + NW * t) + r;
@@ -306,10 +305,16 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         const int gy = row0 + iy;
         const bool ok = (p < PIN) && (gy >= 0) && (gy < H);
         in_lds[t] = ok ? ((iy + ROFF) * PITCH + ix + 1) * SLOT + 16 * h : -1;
-        const T* src = Ximg + ((size_t)(ok ? gy : 0) * W + (ok ? ix : 0)) * CIN + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) xf[t][ks] = *reinterpret_cast<const V8*>(src + 16 * ks);
+        x_off[t] = ((ok ? gy : 0) * W + (ok ? ix : 0)) * CIN + 8 * h;
     }
+    auto load_x = [&](int img) {
+        const T* Ximg = X + (size_t)img * H * W * CIN;
+#pragma unroll
+        for (int t = 0; t < MTIW; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) xf[t][ks] = *reinterpret_cast<const V8*>(Ximg + x_off[t] + 16 * ks);
+    };
+    load_x(blockIdx.y);
 
     // ---- output pixel of this lane: LDS byte address of unit h of each of its 9 taps ----------
     int tapb[9];
@@ -326,10 +331,6 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 
     // project accumulators: row acc_row(g,h) of tile n3 <-> channel 32 n3 + 8q + 4h + i; the bias joins in the epilogue
     f32x16 pacc[NT3];
-#pragma unroll
-    for (int n3 = 0; n3 < NT3; ++n3)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) pacc[n3][g] = 0.0f;
 
     // ================= expand of slice c: E[64 ch][pixels] = PReLU(W1 . X + b1) -> LDS image =================
     typedef ExpStage<T, KS1, CEXP, PW1> Ex;
@@ -386,130 +387,90 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         dw.run(pacc);
     };
 
-    if (MODE == 2) {
-        // Two images, two copies of the weight slices.  Between two barriers a wave expands slice c+1 into one
-        // image and runs depthwise+project of slice c from the other; the two waves that share a SIMD
-        // (w and w + NW/2) take the two phases in opposite order, so one's matrix-core phase runs under
-        // the other's vector phase.  W1 of slice c sits in buffer c&1, W3 likewise.
-        auto fetch_w1 = [&](int c) {
-#pragma unroll
-            for (int i = 0; i < W1_PT; ++i) {
-                const int v = tid + i * NT;
-                if (v < W1_V) wreg1[i] = *reinterpret_cast<const V8*>(W1 + (size_t)c * 64 * CIN + (size_t)v * 8);
-            }
-        };
-        auto fetch_w3 = [&](int c) {
-#pragma unroll
-            for (int i = 0; i < W3_PT; ++i) {
-                const int v = tid + i * NT;
-                if (v < W3_V) wreg3[i] = *reinterpret_cast<const V8*>(W3p + (size_t)(v >> 3) * CEXP + c * 64 + (v & 7) * 8);
-            }
-        };
-        auto store_w1 = [&](int buf) {
-#pragma unroll
-            for (int i = 0; i < W1_PT; ++i) {
-                const int v = tid + i * NT;
-                const int row = v / CH1, ch = v - row * CH1;
-                if (v < W1_V) *reinterpret_cast<V8*>(lds + OFF_W1 + buf * W1_BYTES + row * PW1 + ch * 16) = wreg1[i];
-            }
-        };
-        auto store_w3 = [&](int buf) {
-#pragma unroll
-            for (int i = 0; i < W3_PT; ++i) {
-                const int v = tid + i * NT;
-                if (v < W3_V) *reinterpret_cast<V8*>(lds + OFF_W3 + buf * W3_BYTES + (v >> 3) * PW3 + (v & 7) * 16) = wreg3[i];
-            }
-        };
-        const bool expand_first = (wave & (NW / 2)) == 0;
+    // A workgroup keeps its band and walks over images blockIdx.y, blockIdx.y + gridDim.y, ...: the per-channel
+    // parameters are staged once, and the next image's input fragments and first weight slice are
+    // requested while the current image's last slice and epilogue still run.
+    static_assert(MODE == 0 || MODE == 1, "modes: 0 = one copy of the weight slices, 1 = two");
+    for (int img = blockIdx.y; img < B; img += gridDim.y) {
+        const bool has_next = img + (int)gridDim.y < B;
+        // zero the activation image: borders and out-of-image rows are never written by the expand stage
+        // (the previous image's epilogue used this memory as staging)
+        for (int i = tid; i < ES_BYTES / 16; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         store_w(0);
-        if (NCH > 1) fetch_w1(1);
+        fetch_w(1);
         __syncthreads();
-        expand(0, 0, 0);
-        if (NCH > 1) { store_w1(1); fetch_w3(1); }
-        if (NCH > 2) fetch_w1(2);
-        __syncthreads();
-#pragma unroll 1
-        for (int c = 0; c < NCH; ++c) {
-            if (!expand_first) dwproject(c, c & 1, c & 1);
-            __builtin_amdgcn_sched_barrier(0);       // keep the two stages' registers from overlapping
-            if (c + 1 < NCH) expand(c + 1, (c + 1) & 1, (c + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (expand_first) dwproject(c, c & 1, c & 1);
-            // W1 buffer c&1 held slice c (last read before the previous barrier); W3 buffer (c+1)&1 held slice c-1
-            if (c + 2 < NCH) store_w1(c & 1);
-            if (c + 1 < NCH) store_w3((c + 1) & 1);
-            if (c + 3 < NCH) fetch_w1(c + 3);
-            if (c + 2 < NCH) fetch_w3(c + 2);
-            __syncthreads();
-        }
-    } else if (MODE == 1) {
-        // expand | barrier | depthwise+project, next slice's weights into the other buffer | barrier
-        store_w(0);
-        if (NCH > 1) fetch_w(1);
-        __syncthreads();
-#pragma unroll 1
-        for (int c = 0; c < NCH; ++c) {
-            expand(c, c & 1, 0);
-            __syncthreads();                       // the image of slice c is complete
-            dwproject(c, c & 1, 0);
-            if (c + 1 < NCH) {
-                store_w((c + 1) & 1);              // that buffer was last read before the previous barrier
-                if (c + 2 < NCH) fetch_w(c + 2);
-            }
-            __syncthreads();                       // image and old weights free, new weights visible
-        }
-    } else {
-        // one copy of the weight slices (less LDS, so that two workgroups share a CU and fill each
-        // other's barrier waits): expand | barrier | depthwise+project | barrier | restage | barrier
-        store_w(0);
-        if (NCH > 1) fetch_w(1);
-        __syncthreads();
-#pragma unroll 1
-        for (int c = 0; c < NCH; ++c) {
-            expand(c, 0, 0);
-            __syncthreads();
-            dwproject(c, 0, 0);
-            __syncthreads();
-            if (c + 1 < NCH) {
-                store_w(0);
-                if (c + 2 < NCH) fetch_w(c + 2);
-                __syncthreads();
-            }
-        }
-    }
-
-    // ---- epilogue: accumulators -> f32 pixel rows in LDS -> (+ bias, + shortcut) -> NHWC, 8 bytes per lane -------
-    if (wave < MTO && out_ok) {
-        char* dst = lds + po * P32 + 16 * h;
 #pragma unroll
         for (int n3 = 0; n3 < NT3; ++n3)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<f32x4*>(dst + (32 * n3 + 8 * q) * 4) =
-                    f32x4{pacc[n3][4 * q], pacc[n3][4 * q + 1], pacc[n3][4 * q + 2], pacc[n3][4 * q + 3]};
-    }
-    __syncthreads();
-    {
-        constexpr int G = COUT / 4, UNITS = POUT * G;      // a unit = 4 channels of one pixel
-        const int g = tid % G;
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(b3 + 4 * g);
-        const size_t pix0 = (size_t)img * Ho * Wo + (size_t)y0 * Wo;
-        const T* Xo = X + pix0 * CIN;
-        T* Oo = O + pix0 * COUT;
-#pragma unroll 4
-        for (int u = tid; u < UNITS; u += NT) {
-            const int p = u / G;
-            f32x4 v = *reinterpret_cast<const f32x4*>(lds + p * P32 + g * 16);
-            if (RESID) {
-                const V4 rr = *reinterpret_cast<const V4*>(Xo + (size_t)p * CIN + 4 * g);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] += (float)rr[i];
+            for (int g = 0; g < 16; ++g) pacc[n3][g] = 0.0f;
+        if (MODE == 1) {
+            // expand | barrier | depthwise+project, next slice's weights into the other buffer | barrier
+#pragma unroll 1
+            for (int c = 0; c < NCH; ++c) {
+                expand(c, c & 1, 0);
+                if (c == NCH - 1 && has_next) load_x(img + gridDim.y);   // the fragments are dead after the last expand
+                __syncthreads();                       // the image of slice c is complete
+                dwproject(c, c & 1, 0);
+                if (c + 1 < NCH) {
+                    store_w((c + 1) & 1);              // that buffer was last read before the previous barrier
+                    // one load site for both cases (the next slice, or the next image's first slice, which is
+                    // stored after the epilogue), so the loads stay here, a whole slice ahead of their use
+                    if (c + 2 < NCH || has_next) fetch_w(c + 2 < NCH ? c + 2 : 0);
+                }
+                __syncthreads();                       // image and old weights free, new weights visible
             }
-            V4 o;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = (T)(v[i] + bias[i]);
-            *reinterpret_cast<V4*>(Oo + (size_t)p * COUT + 4 * g) = o;
+        } else {
+            // one copy of the weight slices (less LDS, so that two workgroups share a CU and fill each
+            // other's barrier waits): expand | barrier | depthwise+project | barrier | restage | barrier
+#pragma unroll 1
+            for (int c = 0; c < NCH; ++c) {
+                expand(c, 0, 0);
+                if (c == NCH - 1 && has_next) load_x(img + gridDim.y);
+                __syncthreads();
+                dwproject(c, 0, 0);
+                __syncthreads();
+                if (c + 1 < NCH) {
+                    store_w(0);
+                    if (c + 2 < NCH || has_next) fetch_w(c + 2 < NCH ? c + 2 : 0);
+                    __syncthreads();
+                }
+            }
         }
+
+        // ---- epilogue: accumulators -> f32 pixel rows in LDS -> (+ bias, + shortcut) -> NHWC, 8 bytes per lane -------
+        if (wave < MTO && out_ok) {
+            char* dst = lds + po * P32 + 16 * h;
+    #pragma unroll
+            for (int n3 = 0; n3 < NT3; ++n3)
+    #pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4*>(dst + (32 * n3 + 8 * q) * 4) =
+                        f32x4{pacc[n3][4 * q], pacc[n3][4 * q + 1], pacc[n3][4 * q + 2], pacc[n3][4 * q + 3]};
+        }
+        __syncthreads();
+        {
+            constexpr int G = COUT / 4, UNITS = POUT * G;      // a unit = 4 channels of one pixel
+            const int g = tid % G;
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(b3 + 4 * g);
+            const size_t pix0 = (size_t)img * Ho * Wo + (size_t)y0 * Wo;
+            const T* Xo = X + pix0 * CIN;
+            T* Oo = O + pix0 * COUT;
+    #pragma unroll 4
+            for (int u = tid; u < UNITS; u += NT) {
+                const int p = u / G;
+                f32x4 v = *reinterpret_cast<const f32x4*>(lds + p * P32 + g * 16);
+                if (RESID) {
+                    const V4 rr = *reinterpret_cast<const V4*>(Xo + (size_t)p * CIN + 4 * g);
+    #pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += (float)rr[i];
+                }
+                V4 o;
+    #pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (T)(v[i] + bias[i]);
+                *reinterpret_cast<V4*>(Oo + (size_t)p * COUT + 4 * g) = o;
+            }
+        }
+        if (has_next) __syncthreads();   // staging reads are done before the region is zeroed and restaged
     }
 }
 
@@ -517,25 +478,48 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 template <int CIN, int CEXP, int COUT, int H, int S, int TR, int MODE>
 constexpr int block_lds_bytes() {
     constexpr int RIN = (S == 1) ? TR + 2 : 2 * TR + 1;
-    constexpr int main_bytes = (MODE == 2 ? 2 : 1) * RIN * (H + 2) * 144 +
+    constexpr int main_bytes = RIN * (H + 2) * 144 +
                                (MODE >= 1 ? 2 : 1) * (64 * (CIN * 2 + 16) + COUT * 144) + 4 * CEXP * 4 + 9 * CEXP * 2;
     constexpr int epi_bytes = TR * (H / S) * (COUT * 4 + 16);
     return cmax(main_bytes, epi_bytes);
 }
 
-template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW, int MODE>
+// workgroups of `kernel` that fit on the current device at once (occupancy x compute units)
+static int resident_workgroups(const void* kernel, int threads, int lds_bytes) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, (size_t)lds_bytes) != hipSuccess || per_cu <= 0)
+        per_cu = 1;
+    return cus * per_cu;
+}
+
+template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW, int MODE, bool PERSIST>
 static int launch_block_cfg(const BlockParams& p, const void* x, void* out, int B, hipStream_t s) {
     FRA_REQUIRE(p.cout == COUT, FRA_ERR_ARG, "block: cout %d, fused kernel has %d", p.cout, COUT);
-    const dim3 grid((H / S) / TR, B), block(NW * 64);
+    // PERSIST: one workgroup per band and resident slot, each walking over the images blockIdx.y,
+    // blockIdx.y + gridDim.y, ... in equal shares (the smallest group count that needs only
+    // ceil(B / slots) images per workgroup).  Otherwise one workgroup per band and image, which balances
+    // better when the bands do not divide the resident slots evenly.
+    const int bands = (H / S) / TR;
     constexpr int lds = block_lds_bytes<CIN, CEXP, COUT, H, S, TR, MODE>();
     auto kern = block_kernel<T, CIN, CEXP, COUT, H, S, TR, RESID, NW, MINW, MODE>;
     static bool attr_done = false;   // per instantiation
+    static int slots = 1;            // resident workgroups per band (of the device first used; one process drives one GPU)
     if (!attr_done) {
         FRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        slots = resident_workgroups(reinterpret_cast<const void*>(kern), NW * 64, lds) / bands;
+        if (slots < 1) slots = 1;
         attr_done = true;
     }
+    int groups = B;
+    if (PERSIST) {
+        const int per = (B + slots - 1) / slots;
+        groups = (B + per - 1) / per;
+    }
+    const dim3 grid(bands, groups), block(NW * 64);
     hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)x, (const T*)p.w1, p.b1p, p.s1p, (const T*)p.w2p, p.b2p,
-                       p.s2p, (const T*)p.w3p, p.b3, (T*)out);
+                       p.s2p, (const T*)p.w3p, p.b3, (T*)out, B);
     FRA_HIP(hipGetLastError());
     return FRA_OK;
 }
@@ -545,17 +529,17 @@ static int launch_block_t(const BlockParams& p, const void* x, void* out, int B,
     const int key = p.cin * 1000000 + p.cexp * 1000 + p.h * 10 + p.stride;
     switch (key) {
         case 64 * 1000000 + 128 * 1000 + 56 * 10 + 2:   // conv_23
-            return launch_block_cfg<T, 64, 128, 64, 56, 2, 4, false, 8, 2, 1>(p, x, out, B, s);
+            return launch_block_cfg<T, 64, 128, 64, 56, 2, 4, false, 8, 2, 1, true>(p, x, out, B, s);
         case 64 * 1000000 + 128 * 1000 + 28 * 10 + 1:   // conv_3.*
-            return launch_block_cfg<T, 64, 128, 64, 28, 1, 4, true, 4, 2, 1>(p, x, out, B, s);
+            return launch_block_cfg<T, 64, 128, 64, 28, 1, 4, true, 4, 2, 1, false>(p, x, out, B, s);
         case 64 * 1000000 + 256 * 1000 + 28 * 10 + 2:   // conv_34
-            return launch_block_cfg<T, 64, 256, 128, 28, 2, 7, false, 8, 2, 1>(p, x, out, B, s);
+            return launch_block_cfg<T, 64, 256, 128, 28, 2, 7, false, 8, 2, 1, true>(p, x, out, B, s);
         case 128 * 1000000 + 256 * 1000 + 14 * 10 + 1:  // conv_4.*
-            return launch_block_cfg<T, 128, 256, 128, 14, 1, 14, true, 8, 2, 1>(p, x, out, B, s);
+            return launch_block_cfg<T, 128, 256, 128, 14, 1, 14, true, 8, 2, 1, true>(p, x, out, B, s);
         case 128 * 1000000 + 512 * 1000 + 14 * 10 + 2:  // conv_45
-            return launch_block_cfg<T, 128, 512, 128, 14, 2, 7, false, 8, 2, 1>(p, x, out, B, s);
+            return launch_block_cfg<T, 128, 512, 128, 14, 2, 7, false, 8, 2, 1, true>(p, x, out, B, s);
         case 128 * 1000000 + 256 * 1000 + 7 * 10 + 1:   // conv_5.*
-            return launch_block_cfg<T, 128, 256, 128, 7, 1, 7, true, 8, 2, 1>(p, x, out, B, s);
+            return launch_block_cfg<T, 128, 256, 128, 7, 1, 7, true, 8, 2, 1, true>(p, x, out, B, s);
         default: break;
     }
     FRA_REQUIRE(false, FRA_ERR_ARG, "block: no fused kernel for cin=%d cexp=%d h=%d stride=%d", p.cin, p.cexp, p.h,

@@ -20,7 +20,7 @@ def _loader(left, right, bs):
 
 def test_get_feature_and_10fold_vs_oracle(hip_model, device, state_dict_np):
     pairs = 200
-    left, right, ds = synthetic.pair_crops(pairs, seed=6, noise=0.9)
+    left, right, ds = synthetic.pair_crops(pairs, seed=6, noise=0.3)
     fl, fr = Evaluation.getFeature(hip_model, _loader(left, right, 50), device, flip=True)
     assert fl.device.type == "cpu" and fl.shape == (pairs, 512) and fl.dtype == torch.float32
     embed = lambda x: mobilefacenet_ref.forward(state_dict_np, x)      # noqa: E731
@@ -30,8 +30,12 @@ def test_get_feature_and_10fold_vs_oracle(hip_model, device, state_dict_np):
     for method in ("l2_distance", "cos_distance"):
         acc, thr = Evaluation.evaluation_10_fold(fl, fr, ds, method)
         oacc, othr = evaluation_ref.evaluation_10_fold(ol.numpy(), orr.numpy(), ds.folds, ds.flags, method)
+        # the protocol itself is exact: the oracle's 10-fold on the GPU features gives the same numbers
+        pacc, pthr = evaluation_ref.evaluation_10_fold(fl.numpy(), fr.numpy(), ds.folds, ds.flags, method)
+        assert np.array_equal(acc, pacc) and np.array_equal(thr, pthr)
         print(method, "acc %.3f vs oracle %.3f; thr %.4f vs %.4f" % (acc.mean() * 100, oacc.mean() * 100, thr.mean(), othr.mean()))
-        # 200 pairs -> one pair is 0.5 pt; with embeddings at cosine >= 0.9999 no decision should move
+        # 200 pairs at ~99 % accuracy (the regime of the real benchmarks): one pair is 0.5 pt, and with
+        # embeddings at cosine >= 0.9999 at most one borderline pair may change sides
         assert abs(acc.mean() - oacc.mean()) * 100 <= 0.5 + 1e-9
         assert abs(thr.mean() - othr.mean()) < 5e-3
     fl2, _ = Evaluation.getFeature(hip_model, _loader(left[:20], right[:20], 7), device, flip=False)

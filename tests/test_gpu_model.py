@@ -75,6 +75,19 @@ def test_batch_independence_and_chunking(hip_model, device):
     assert torch.equal(full, chunked)
 
 
+def test_large_batch_rows_match_small_batches(hip_model, device):
+    """A batch large enough that every workgroup of the block kernels walks over several images
+    gives, row for row, what small batches give."""
+    B = 700
+    x = torch.from_numpy(synthetic.make_crops(64, 11)).to(device).repeat(11, 1, 1, 1)[:B].contiguous()
+    x += torch.linspace(-0.2, 0.2, B, device=device).view(B, 1, 1, 1)
+    full = hip_model(x).cpu()
+    for lo in (0, 255, 256, 511, 693):
+        part = hip_model(x[lo:lo + 7]).cpu()
+        assert torch.equal(full[lo:lo + 7], part), lo
+    assert torch.isfinite(full).all()
+
+
 def test_fused_and_unfused_schedules_agree(hip_model, device, state_dict_np):
     """One kernel per block vs one kernel per conv: same arithmetic up to summation order."""
     xn = synthetic.make_crops(3, 21)
