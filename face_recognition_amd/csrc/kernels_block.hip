@@ -531,7 +531,7 @@ static int launch_block_t(const BlockParams& p, const void* x, void* out, int B,
         case 64 * 1000000 + 128 * 1000 + 56 * 10 + 2:   // conv_23
             return launch_block_cfg<T, 64, 128, 64, 56, 2, 4, false, 8, 2, 1, true>(p, x, out, B, s);
         case 64 * 1000000 + 128 * 1000 + 28 * 10 + 1:   // conv_3.*
-            return launch_block_cfg<T, 64, 128, 64, 28, 1, 4, true, 4, 2, 1, false>(p, x, out, B, s);
+            return launch_block_cfg<T, 64, 128, 64, 28, 1, 7, true, 8, 2, 1, true>(p, x, out, B, s);
         case 64 * 1000000 + 256 * 1000 + 28 * 10 + 2:   // conv_34
             return launch_block_cfg<T, 64, 256, 128, 28, 2, 7, false, 8, 2, 1, true>(p, x, out, B, s);
         case 128 * 1000000 + 256 * 1000 + 14 * 10 + 1:  // conv_4.*
