@@ -211,6 +211,22 @@ def latency(net, dev):
     return out
 
 
+def verification_timing(dev):
+    """10-fold protocol on 6000 synthetic pairs: features on the device vs the host numpy path (same results)."""
+    from face_recognition_amd import Evaluation
+    fl, fr, ds = synthetic.planted_features(6000, seed=21, same_cos=0.5, diff_cos=0.12)
+    dl, dr = torch.from_numpy(fl).to(dev), torch.from_numpy(fr).to(dev)
+    Evaluation.evaluation_10_fold(dl, dr, ds, "cos_distance")            # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); a_dev, t_dev = Evaluation.evaluation_10_fold(dl, dr, ds, "cos_distance")
+    t1 = time.perf_counter(); a_host, t_host = Evaluation.evaluation_10_fold(fl, fr, ds, "cos_distance")
+    t2 = time.perf_counter()
+    return {"pairs": 6000, "method": "cos_distance", "device_ms": round((t1 - t0) * 1e3, 1),
+            "host_numpy_ms": round((t2 - t1) * 1e3, 1),
+            "identical": bool(np.array_equal(a_dev, a_host) and np.array_equal(t_dev, t_host)),
+            "accuracy": round(float(a_dev.mean()) * 100, 3)}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -305,6 +321,7 @@ def main():
         result["sum_kernel_ms"] = round(total_ms, 4)
         if not args.no_latency:
             result["latency_us"] = latency(net, dev)
+            result["verification_10fold"] = verification_timing(dev)
     if not args.no_search:
         s = run_search(args, rank, world, dev, dist)
         if rank == 0:

@@ -12,6 +12,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from . import _lib
 from .face_model import MobileFaceNet, l2_norm, tta_combine  # noqa: F401
 
 
@@ -58,9 +59,11 @@ def getThreshold(scores, flags, thrNum, method):
     return np.mean(thresholds[max_index])
 
 
-def getFeature(net, dataloader, device, flip=True):
+def getFeature(net, dataloader, device, flip=True, keep_on_device=False):
     """Evaluation.py:36-66.  ``dataloader`` yields lists ``[L, flip(L), R, flip(R)]`` of f32
-    [b,3,112,112]; returns CPU f32 tensors (featureLs, featureRs) in loader order."""
+    [b,3,112,112]; returns CPU f32 tensors (featureLs, featureRs) in loader order.
+    ``keep_on_device=True`` (not in the reference) leaves them on the HIP device for
+    ``evaluation_10_fold``'s device path."""
     featureLs, featureRs = [], []
     for det in dataloader:
         det = [d.to(device, non_blocking=True) for d in det]
@@ -72,8 +75,8 @@ def getFeature(net, dataloader, device, flip=True):
                 featureR = tta_combine(res[2], res[3])
             else:
                 featureL, featureR = res[0], res[2]
-        featureLs.append(featureL.cpu())
-        featureRs.append(featureR.cpu())
+        featureLs.append(featureL if keep_on_device else featureL.cpu())
+        featureRs.append(featureR if keep_on_device else featureR.cpu())
     if not featureLs:
         return None, None
     return torch.cat(featureLs, 0), torch.cat(featureRs, 0)
@@ -86,6 +89,8 @@ def evaluation_10_fold(featureL, featureR, dataset, method="l2_distance"):
     mean is subtracted from the arrays carried into the next fold (:86-89), so the centring
     accumulates across folds exactly as it does there.
     """
+    if isinstance(featureL, torch.Tensor) and featureL.is_cuda:
+        return _evaluation_10_fold_device(featureL, featureR, dataset, method)
     ACCs = np.zeros(10)
     threshold = np.zeros(10)
     fold = np.array(dataset.folds).reshape(1, -1)
@@ -110,4 +115,43 @@ def evaluation_10_fold(featureL, featureR, dataset, method="l2_distance"):
             raise ValueError(f"unknown method {method!r}")
         threshold[i] = getThreshold(scores[valFold[0]], flags[valFold[0]], 10000, method)
         ACCs[i] = getAccuracy(scores[testFold[0]], flags[testFold[0]], threshold[i], method)
+    return ACCs, threshold
+
+
+def _evaluation_10_fold_device(featureL, featureR, dataset, method):
+    """evaluation_10_fold with the features resident on the HIP device: centring, normalisation and
+    scoring of every fold run there (``ev_fold_scores``, float32 operations in numpy's order, so the
+    scores equal the host path's bit for bit); the threshold search and the accuracy count take the
+    P scores of a fold on the host."""
+    if method not in ("l2_distance", "cos_distance"):
+        raise ValueError(f"unknown method {method!r}")
+    if not (isinstance(featureR, torch.Tensor) and featureR.device == featureL.device):
+        raise RuntimeError("evaluation_10_fold: featureL and featureR must be on the same device")
+    if featureL.shape != featureR.shape or featureL.dim() != 2:
+        raise RuntimeError(f"evaluation_10_fold: feature shapes {tuple(featureL.shape)} / {tuple(featureR.shape)}")
+    lib = _lib.load()
+    dev = featureL.device
+    P, D = int(featureL.shape[0]), int(featureL.shape[1])
+    fold = np.array(dataset.folds).reshape(-1)
+    flags = np.array(dataset.flags).reshape(-1)
+    if fold.shape[0] != P or flags.shape[0] != P:
+        raise RuntimeError(f"evaluation_10_fold: {P} pairs but {fold.shape[0]} folds / {flags.shape[0]} flags")
+    ACCs = np.zeros(10)
+    threshold = np.zeros(10)
+    with torch.cuda.device(dev):
+        # private copies: the reference rebinds its local arrays and leaves the caller's untouched
+        fl = featureL.detach().to(torch.float32).contiguous().clone()
+        fr = featureR.detach().to(torch.float32).contiguous().clone()
+        mu = torch.empty(D, dtype=torch.float32, device=dev)
+        scores = torch.empty(P, dtype=torch.float32, device=dev)
+        for i in range(10):
+            val = fold != i
+            test = fold == i
+            mask = torch.from_numpy(val.astype(np.uint8)).to(dev)
+            _lib.check(lib.ev_fold_scores(fl.data_ptr(), fr.data_ptr(), mask.data_ptr(), int(val.sum()), P, D,
+                                          0 if method == "l2_distance" else 1, mu.data_ptr(), scores.data_ptr(),
+                                          _lib.current_stream_ptr(dev)), "ev_fold_scores")
+            sc = scores.cpu().numpy()
+            threshold[i] = getThreshold(sc[val], flags[val], 10000, method)
+            ACCs[i] = getAccuracy(sc[test], flags[test], threshold[i], method)
     return ACCs, threshold

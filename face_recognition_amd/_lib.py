@@ -54,6 +54,7 @@ SIGNATURES = {
     "fb_merge_topk": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "fb_threshold_score": (_I, [_P, _P, _P, _I, _D, _P]),
     "fb_destroy": (_I, [_P]),
+    "ev_fold_scores": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

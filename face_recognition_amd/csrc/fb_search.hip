@@ -463,7 +463,12 @@ __global__ __launch_bounds__(256) void threshold_score_kernel(const float* __res
     const float m = minimum[i];
     if (m > limit) idx[i] = -1;                                   // cam_demo.py:100
     // cam_demo.py:105 -- multiply and add round separately in the reference, so no fused multiply-add
-    const float sc = __fadd_rn(__fmul_rn(m, -80.0f), 156.0f);
+    // (plain operators under the pragma: the __fmul_rn / __fadd_rn helpers fuse after inlining)
+    float sc;
+    {
+#pragma clang fp contract(off)
+        sc = m * -80.0f + 156.0f;
+    }
     score[i] = fminf(fmaxf(sc, 0.0f), 100.0f);
 }
 

@@ -165,6 +165,21 @@ int fb_threshold_score(const float* minimum, int64_t* idx_io, float* score_100, 
 
 int fb_destroy(fb_handle* h);
 
+/* ---- verification protocol on the device -------------------------------------------------------
+ * One fold of evaluation_10_fold (Mobilefacenet/Evaluation.py:83-94):
+ *     mu = mean(concat(fl[val], fr[val]), axis 0);  fl -= mu; fr -= mu;
+ *     fl /= |fl| (row-wise);  fr /= |fr|;
+ *     scores = sum((fl - fr)^2, axis 1)   (method 0, "l2_distance")
+ *            = sum(fl * fr, axis 1)       (method 1, "cos_distance")
+ * fl, fr: dev f32 [P,D], UPDATED IN PLACE -- the reference re-assigns the centred, normalised
+ * arrays inside its fold loop (:86-89), so the centring accumulates from fold to fold; call this once
+ * per fold on the same buffers.  val_mask: dev uint8 [P], 1 = pair belongs to the folds the mean is
+ * taken over (n_val of them).  mu_scratch: dev f32 [D].  scores_out: dev f32 [P] (all pairs).
+ * Every float32 operation is issued in numpy's order, so the scores equal the reference's bit for bit.
+ * D in {128, 256, 512}. */
+int ev_fold_scores(float* fl, float* fr, const uint8_t* val_mask, int n_val, int P, int D, int method,
+                   float* mu_scratch, float* scores_out, fra_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

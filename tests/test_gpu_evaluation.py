@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+import os
+
 from conftest import cosine_rows
 from face_recognition_amd import Evaluation, synthetic
 from oracle import evaluation_ref, mobilefacenet_ref
@@ -55,3 +57,62 @@ def test_accuracy_within_point_one_on_perturbed_features(device):
         a, _ = Evaluation.evaluation_10_fold(fl, fr, ds, method)
         b, _ = Evaluation.evaluation_10_fold(fl2, fr2, ds, method)
         assert abs(a.mean() - b.mean()) * 100 <= 0.1
+
+
+def test_device_10fold_equals_reference_golden(device, golden_dir):
+    """Features resident on the GPU: thresholds and accuracies bit-identical to the reference's run."""
+    z = np.load(os.path.join(golden_dir, "eval10fold.npz"))
+    import ast
+    for tag, pairs in (("p600", 600), ("p1200_hard", 1200), ("p6000", 6000)):
+        seed = int(z[f"{tag}_seed"])                       # the seeds / arguments make_golden.py used
+        kw = ast.literal_eval(str(z[f"{tag}_kw"]))
+        fl, fr, ds = synthetic.planted_features(pairs, seed=seed, **kw)
+        dl, dr = torch.from_numpy(fl).to(device), torch.from_numpy(fr).to(device)
+        keep = dl.clone()
+        for method in ("l2_distance", "cos_distance"):
+            accs, thr = Evaluation.evaluation_10_fold(dl, dr, ds, method)
+            assert np.array_equal(accs, z[f"{tag}_{method}_accs"]), (tag, method)
+            assert np.array_equal(thr, z[f"{tag}_{method}_thr"]), (tag, method)
+        assert torch.equal(dl, keep)          # the caller's tensors are left alone
+
+
+@pytest.mark.parametrize("D", [128, 256, 512])
+def test_device_fold_scores_bit_identical_to_numpy(device, D):
+    """ev_fold_scores against the reference's array expressions (Evaluation.py:84-94), two folds in a row
+    so that the carried-over centring is covered; ragged pair count."""
+    from face_recognition_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(D)
+    P = 1237
+    fl = (rng.standard_normal((P, D)) * 0.2 + 0.05).astype(np.float32)
+    fr = (fl * 0.5 + rng.standard_normal((P, D)) * 0.2).astype(np.float32)
+    folds = rng.integers(0, 10, P)
+    dl, dr = torch.from_numpy(fl).to(device), torch.from_numpy(fr).to(device)
+    mu = torch.empty(D, device=device)
+    sc = torch.empty(P, device=device)
+    for method_id, method in ((0, "l2_distance"), (1, "cos_distance")):
+        for i in (3, 4):
+            val = folds != i
+            m = np.mean(np.concatenate((fl[val], fr[val]), 0), 0)[None]
+            fl, fr = fl - m, fr - m
+            fl = fl / np.expand_dims(np.sqrt(np.sum(np.power(fl, 2), 1)), 1)
+            fr = fr / np.expand_dims(np.sqrt(np.sum(np.power(fr, 2), 1)), 1)
+            want = np.sum(np.power(fl - fr, 2), 1) if method_id == 0 else np.sum(np.multiply(fl, fr), 1)
+            mask = torch.from_numpy(val.astype(np.uint8)).to(device)
+            _lib.check(lib.ev_fold_scores(dl.data_ptr(), dr.data_ptr(), mask.data_ptr(), int(val.sum()), P, D, method_id,
+                                          mu.data_ptr(), sc.data_ptr(), _lib.current_stream_ptr(device)), "ev_fold_scores")
+            assert np.array_equal(sc.cpu().numpy(), want), (method, i)
+            assert np.array_equal(dl.cpu().numpy(), fl) and np.array_equal(dr.cpu().numpy(), fr)
+    with pytest.raises(RuntimeError, match="feature width"):
+        _lib.check(lib.ev_fold_scores(dl.data_ptr(), dr.data_ptr(), mask.data_ptr(), 5, P, 100, 0, mu.data_ptr(),
+                                      sc.data_ptr(), _lib.current_stream_ptr(device)), "ev_fold_scores")
+
+
+def test_get_feature_on_device_feeds_device_10fold(hip_model, device):
+    pairs = 40
+    left, right, ds = synthetic.pair_crops(pairs, seed=9, noise=0.3)
+    fl, fr = Evaluation.getFeature(hip_model, _loader(left, right, 20), device, flip=True, keep_on_device=True)
+    assert fl.is_cuda and fr.is_cuda
+    a_dev, t_dev = Evaluation.evaluation_10_fold(fl, fr, ds, "cos_distance")
+    a_host, t_host = Evaluation.evaluation_10_fold(fl.cpu(), fr.cpu(), ds, "cos_distance")
+    assert np.array_equal(a_dev, a_host) and np.array_equal(t_dev, t_host)

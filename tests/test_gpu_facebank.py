@@ -40,6 +40,8 @@ def test_match_vs_reference_expression(device, Q, N):
     assert np.array_equal(idx.cpu().numpy(), want_idx.numpy())
     assert np.allclose(mn.cpu().numpy(), want_min.numpy(), rtol=1e-5, atol=2e-6)
     assert np.allclose(sc.cpu().numpy(), want_score.numpy(), rtol=1e-5, atol=3e-4)
+    # given the same distances, the score line of cam_demo.py:105 (multiply, then add, then clamp) is exact
+    assert torch.equal(sc.cpu(), torch.clamp(mn.cpu() * -80 + 156, 0, 100))
 
 
 def test_exact_ties_pick_lowest_index(device):
