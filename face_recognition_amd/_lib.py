@@ -50,6 +50,8 @@ SIGNATURES = {
     "fb_fill": (_I, [_P, _L, _P, _I, _L]),
     "fb_rows": (_L, [_P]),
     "fb_reserve": (_I, [_P, _I]),
+    "fb_export_packed": (_I, [_P, _L, _L, _P, _I, _P, _I]),
+    "fb_import_packed": (_I, [_P, _L, _L, _P, _I, _P, _I]),
     "fb_search_l2_topk": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "fb_merge_topk": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "fb_threshold_score": (_I, [_P, _P, _P, _I, _D, _P]),

@@ -661,6 +661,40 @@ int fb_fill(fb_handle* h, int64_t row0, const float* rows, int rows_is_device, i
 
 int64_t fb_rows(const fb_handle* h) { return h ? h->N : -1; }
 
+// packed rows (16-bit [n][D]) and their bias terms, exactly as the search kernel reads them
+static int copy_packed(fb_handle* h, int64_t row0, int64_t n, void* rows16, int rows_is_device, float* negh,
+                       int negh_is_device, bool to_handle, const char* what) {
+    FRA_REQUIRE(h && rows16 && negh, FRA_ERR_ARG, "%s: null pointer", what);
+    FRA_REQUIRE(h->store == FRA_F16 || h->store == FRA_BF16, FRA_ERR_ARG, "%s: the gallery stores fp32 rows, nothing is packed",
+                what);
+    FRA_REQUIRE(row0 >= 0 && n >= 0 && row0 + n <= h->N, FRA_ERR_ARG, "%s: rows [%lld,%lld) outside [0,%lld)", what,
+                (long long)row0, (long long)(row0 + n), (long long)h->N);
+    if (n == 0) return FRA_OK;
+    FRA_HIP(hipSetDevice(h->device));
+    char* hr = static_cast<char*>(h->rows) + (size_t)row0 * h->D * 2;
+    float* hn = h->negh + row0;
+    const size_t rb = (size_t)n * h->D * 2, nb = (size_t)n * 4;
+    if (to_handle) {
+        FRA_HIP(hipMemcpy(hr, rows16, rb, rows_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        FRA_HIP(hipMemcpy(hn, negh, nb, negh_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    } else {
+        FRA_HIP(hipMemcpy(rows16, hr, rb, rows_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+        FRA_HIP(hipMemcpy(negh, hn, nb, negh_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    }
+    return FRA_OK;
+}
+
+int fb_export_packed(fb_handle* h, int64_t row0, int64_t n, void* rows16_out, int rows_is_device, float* negh_out,
+                     int negh_is_device) {
+    return copy_packed(h, row0, n, rows16_out, rows_is_device, negh_out, negh_is_device, false, "fb_export_packed");
+}
+
+int fb_import_packed(fb_handle* h, int64_t row0, int64_t n, const void* rows16, int rows_is_device, const float* negh,
+                     int negh_is_device) {
+    return copy_packed(h, row0, n, const_cast<void*>(rows16), rows_is_device, const_cast<float*>(negh), negh_is_device,
+                       true, "fb_import_packed");
+}
+
 int fb_reserve(fb_handle* h, int max_queries) {
     FRA_REQUIRE(h && max_queries > 0, FRA_ERR_ARG, "fb_reserve: bad argument");
     FRA_HIP(hipSetDevice(h->device));

@@ -141,6 +141,16 @@ int fb_create(fb_handle** out, int device, const float* gallery, int gallery_is_
  * large shard be produced piecewise on the device.  Synchronous. */
 int fb_fill(fb_handle* h, int64_t row0, const float* rows, int rows_is_device, int64_t n);
 int64_t fb_rows(const fb_handle* h);
+/* Packed form of rows [row0, row0+n) of a 16-bit gallery: the 16-bit rows [n,D] and the fp32 bias terms
+ * -|g|^2/2 [n] exactly as the search kernel reads them.  Export after fb_fill and import into a gallery
+ * of the same store dtype reproduce every search result bit for bit and skip the fp32 -> 16-bit
+ * conversion; this is what a gallery file on disk holds (the reference keeps its facebank as one fp32
+ * tensor in facebank.pth, facebank.py:72-75,79-83).  Host or device pointers; synchronous. */
+int fb_export_packed(fb_handle* h, int64_t row0, int64_t n, void* rows16_out, int rows_is_device, float* negh_out,
+                     int negh_is_device);
+int fb_import_packed(fb_handle* h, int64_t row0, int64_t n, const void* rows16, int rows_is_device, const float* negh,
+                     int negh_is_device);
+
 /* Pre-size the handle's internal scratch for searches of up to max_queries queries, so that no
  * search of that size allocates (e.g. before capturing searches into a hipGraph).  Scratch only
  * grows, and blocks already used are kept until fb_destroy, so captured graphs stay valid. */

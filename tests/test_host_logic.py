@@ -141,3 +141,17 @@ def test_load_facebank_roundtrip(tmp_path, golden_dir):
     np.save(tmp_path / "names", z["names"])
     emb, names = load_facebank(str(tmp_path))
     assert emb.shape == (5, 512) and emb.dtype == torch.float32 and names.shape == (6,) and names[0] == ""
+
+
+def test_store_shard_overlap_arithmetic():
+    """Which part of which shard file a rank reads (gallery_store._overlaps): pure host logic."""
+    from face_recognition_amd import gallery_store as gs
+    meta = {"shards": [{"rows": 3000, "row0": 0}, {"rows": 3000, "row0": 3000}, {"rows": 1007, "row0": 6000}]}
+    assert list(gs._overlaps(meta, 0, 7007)) == [(0, 0, 3000, 0), (1, 0, 3000, 3000), (2, 0, 1007, 6000)]
+    assert list(gs._overlaps(meta, 2500, 3100)) == [(0, 2500, 500, 0), (1, 0, 100, 500)]
+    assert list(gs._overlaps(meta, 6000, 6001)) == [(2, 0, 1, 0)]
+    assert list(gs._overlaps(meta, 7007, 8000)) == []
+    ids = gs._as_ids(None, 4)
+    assert ids.tolist() == [1, 2, 3, 4] and ids.dtype == np.int32
+    with pytest.raises(RuntimeError):
+        gs._as_ids([1, 2], 3)
