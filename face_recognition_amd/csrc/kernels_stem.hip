@@ -17,11 +17,73 @@
 // row 16g+8a+4h+i computes output channel 16g+8h+4a+i, so the 8 values a lane holds per
 // 16-channel group are 8 CONSECUTIVE channels and travel as one 16-byte unit.  Slope arrays hold
 // (PReLU slope - 1).
+//
+// LDS image: 64 pixel slots of 128 bytes per row; unit u (8 channels) of slot s sits at u ^ (s & 7).
+// The stem stage writes it from the MFMA layout (lane = pixel, two units per lane), which the XOR
+// keeps conflict free; the depthwise stage reads it with lane = (pixel = lane >> 3, unit = lane & 7),
+// so eight lanes cover one whole slot, a wave's store is 1 KB of contiguous NHWC output, and a lane
+// works on the same 8 channels for the whole kernel: its 3x3 weights, bias and slopes live in
+// registers.  With 64 slots per row the XOR key of a tap does not depend on the row, so the nine
+// tap addresses are three lane registers plus immediates.  The reads run three taps ahead of the
+// FMAs through a register ring with counted waits (LDS returns data in order).
 #include "common.h"
 
 namespace fra {
 
-__device__ __forceinline__ int eswz2(int slot) { return (slot >> 1) & 7; }   // as eswz() in kernels_block.hip
+#define STEM_LDS_READ16(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+constexpr int SD_PITCH = 64;                 // pixel slots per image row in LDS
+constexpr int SD_PD = 3, SD_RING = SD_PD + 1;
+
+// depthwise stage of one wave: TR output rows x 8 pixels x 64 channels, 9 taps per row
+template <typename T, int TR> struct StemDwStage {
+    typedef typename vec8<T>::type V8;
+    static constexpr int STEPS = 9 * TR;
+    V8 er[SD_RING];
+    V8 wk[9];
+    f32x4 b2a, b2b, s2a, s2b;
+    float d[8];
+    int eb[3];          // LDS address of this lane's unit in the slots of column x + kx, row 0
+    T* out;             // this lane's output address in row 0 of the band
+
+    template <int ST> __device__ __forceinline__ void issue() {
+        constexpr int row = ST / 9, tap = ST % 9, ky = tap / 3, kx = tap % 3;
+        STEM_LDS_READ16(er[ST % SD_RING], eb[kx], (row + ky) * SD_PITCH * 128);
+    }
+    template <int ST = 0> __device__ __forceinline__ void preamble() {
+        if constexpr (ST < SD_PD) { issue<ST>(); preamble<ST + 1>(); }
+    }
+    template <int ST = 0> __device__ __forceinline__ void run() {
+        if constexpr (ST < STEPS) {
+            constexpr int row = ST / 9, tap = ST % 9, slot = ST % SD_RING;
+            if constexpr (ST + SD_PD < STEPS) issue<ST + SD_PD>();
+            // reads issued after this step's: the next min(PD, steps left) taps
+            constexpr int ahead = (ST + SD_PD < STEPS ? SD_PD : STEPS - 1 - ST);
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(er[slot]) : "n"(ahead));
+            if constexpr (tap == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    d[j] = fmaf((float)er[slot][j], (float)wk[0][j], b2a[j]);
+                    d[4 + j] = fmaf((float)er[slot][4 + j], (float)wk[0][4 + j], b2b[j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = fmaf((float)er[slot][j], (float)wk[tap][j], d[j]);
+            }
+            if constexpr (tap == 8) {
+                V8 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = (T)fmaf(fminf(d[j], 0.0f), s2a[j], d[j]);                  // PReLU: s2 = slope - 1
+                    o[4 + j] = (T)fmaf(fminf(d[4 + j], 0.0f), s2b[j], d[4 + j]);
+                }
+                *reinterpret_cast<V8*>(out + (size_t)row * 56 * 64) = o;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            run<ST + 1>();
+        }
+    }
+};
 
 template <typename T, bool U8, int TR, int NW, int MINW>
 __global__ __launch_bounds__(NW * 64, MINW)
@@ -32,10 +94,11 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, const T* __restrict__
     typedef typename vec4<T>::type V4;
     constexpr int NT = NW * 64;
     constexpr int H = 56, W = 56, HI = 112;
-    constexpr int RIN = TR + 2, PITCH = W + 2;
+    constexpr int RIN = TR + 2, PITCH = SD_PITCH;
     constexpr int PIN = RIN * W, POUT = TR * W;
     constexpr int MTI = (PIN + 31) / 32, MTO = (POUT + 31) / 32;
-    constexpr int MTIW = (MTI + NW - 1) / NW, MTOW = (MTO + NW - 1) / NW;
+    constexpr int MTIW = (MTI + NW - 1) / NW;
+    static_assert(W % 8 == 0 && W / 8 <= NW && PITCH >= W + 2, "depthwise stage: one wave per 8-pixel column group");
     constexpr int ES_BYTES = RIN * PITCH * 128;
     // staged input: 4 planes (3 channels + one all-zero plane for the 5 padding taps) of NR rows x PW columns;
     // input column x sits at column x + 4, so groups of 4 columns line up with 16-byte source loads
@@ -177,7 +240,7 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, const T* __restrict__
                         }
                     }
                     const int u = 4 * m + 2 * g + h;       // channels [8u, 8u+8)
-                    *reinterpret_cast<V8*>(es + slot * 128 + ((u ^ eswz2(slot)) << 4)) = o;
+                    *reinterpret_cast<V8*>(es + slot * 128 + ((u ^ (slot & 7)) << 4)) = o;
                 }
             }
         }
@@ -185,55 +248,31 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, const T* __restrict__
     __syncthreads();
 
     // ================= depthwise 3x3 + PReLU from the LDS image -> NHWC =================
-    T* Oimg = O + (size_t)img * H * W * 64;
-#pragma unroll 1
-    for (int t = 0; t < MTOW; ++t) {
-        if (wave + NW * t >= MTO) break;      // wave-uniform
-        const int po = 32 * (wave + NW * t) + r;
-        const bool ok = po < POUT;
-        const int pc = ok ? po : 0;
-        const int oy = pc / W, ox = pc - oy * W;
-        int tap_off[9];
+    if (wave < W / 8) {                       // wave-uniform; wave w owns output columns 8 w .. 8 w + 7 of every row
+        // this lane's column and its 8 channels; everything that depends only on them stays in registers
+        StemDwStage<T, TR> dw;
+        const int dpx = lane >> 3, du = lane & 7;
+        const int x = 8 * wave + dpx;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int k = 0; k < 9; ++k) dw.wk[k] = *reinterpret_cast<const V8*>(lds + OFF_W2 + (k * 64 + 8 * du) * 2);
+        dw.b2a = *reinterpret_cast<const f32x4*>(lds + OFF_B2 + 32 * du);
+        dw.b2b = *reinterpret_cast<const f32x4*>(lds + OFF_B2 + 32 * du + 16);
+        dw.s2a = *reinterpret_cast<const f32x4*>(lds + OFF_S2 + 32 * du);
+        dw.s2b = *reinterpret_cast<const f32x4*>(lds + OFF_S2 + 32 * du + 16);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int slot = (oy + ky) * PITCH + ox + kx;
-                tap_off[ky * 3 + kx] = slot * 128 + (eswz2(slot) << 4);
-            }
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const int u = 2 * s4 + h;
-            const f32x4 b2a = *reinterpret_cast<const f32x4*>(lds + OFF_B2 + u * 32),
-                        b2b = *reinterpret_cast<const f32x4*>(lds + OFF_B2 + u * 32 + 16);
-            float d[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { d[j] = b2a[j]; d[4 + j] = b2b[j]; }
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const V8 e = *reinterpret_cast<const V8*>(es + (tap_off[ky * 3 + kx] ^ (u << 4)));
-                    const V8 wk = *reinterpret_cast<const V8*>(lds + OFF_W2 + ((ky * 3 + kx) * 64 + 8 * u) * 2);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) d[j] = fmaf((float)e[j], (float)wk[j], d[j]);
-                }
-            const f32x4 s2a = *reinterpret_cast<const f32x4*>(lds + OFF_S2 + u * 32),
-                        s2b = *reinterpret_cast<const f32x4*>(lds + OFF_S2 + u * 32 + 16);
-            V8 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o[j] = (T)fmaf(fminf(d[j], 0.0f), s2a[j], d[j]);                  // PReLU: s2 = slope - 1
-                o[4 + j] = (T)fmaf(fminf(d[4 + j], 0.0f), s2b[j], d[4 + j]);
-            }
-            if (ok) *reinterpret_cast<V8*>(Oimg + ((size_t)(y0 + oy) * W + ox) * 64 + 8 * u) = o;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int col = x + kx;           // LDS column of tap kx (column 0 is the left border)
+            dw.eb[kx] = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + col * 128 + ((du ^ (col & 7)) << 4);
         }
+        dw.out = O + ((size_t)img * H * W + (size_t)y0 * W + x) * 64 + 8 * du;
+        dw.preamble();
+        dw.run();
     }
 }
 
 template <typename T, bool U8, int TR, int NW, int MINW>
 static int launch_stemdw_cfg(const StemDwParams& p, const void* x, int n_src, void* out, int B, hipStream_t s) {
-    constexpr int lds = (TR + 2) * 58 * 128 + 4 * (2 * TR + 5) * 120 * 2 + 9 * 64 * 2 + 4 * 256;
+    constexpr int lds = (TR + 2) * SD_PITCH * 128 + 4 * (2 * TR + 5) * 120 * 2 + 9 * 64 * 2 + 4 * 256;
     auto kern = stemdw_kernel<T, U8, TR, NW, MINW>;
     static bool attr_done = false;
     if (!attr_done) {
