@@ -119,61 +119,83 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, const T* __restrict__
     const int y0 = band * TR, row0 = y0 - 1;
     const int rin0 = 2 * row0 - 1;                 // input row held by LDS input row 0
 
+    // ---- prologue.  Every global load of the prologue is issued before the first use of any of them, so the
+    // workgroup pays one memory latency, not one per loop; the LDS zeroing runs while they are in flight.
+    // Input band: column group g holds input columns 4(g-1) .. 4(g-1)+3 (g = 0 and g = NG-1 are padding).
+    constexpr int NIN = U8 ? NR * NG : 3 * NR * NG;         // staging items: 4 pixels of one row (x 3 channels for U8)
+    constexpr int IN_IT = (NIN + NT - 1) / NT;
+    f32x4 vin[U8 ? 1 : IN_IT];
+    unsigned win[U8 ? IN_IT : 1][3];
+    bool in_ok[IN_IT];
+#pragma unroll
+    for (int it = 0; it < IN_IT; ++it) {
+        const int i = tid + it * NT;
+        const int g = i % NG, cr = i / NG;                   // cr = c * NR + ry (fp32) or ry (uint8)
+        const int ry = U8 ? cr : cr % NR, c = U8 ? 0 : cr / NR;
+        const int yin = rin0 + ry;
+        in_ok[it] = i < NIN && g >= 1 && g <= 28 && yin >= 0 && yin < HI;
+        const int x0 = flip ? 108 - 4 * (g - 1) : 4 * (g - 1);
+        if (!U8) {
+            vin[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (in_ok[it])
+                vin[it] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(Xv) + (size_t)src * 3 * HI * HI +
+                                                          ((size_t)c * HI + yin) * HI + x0);
+        } else {
+            win[it][0] = win[it][1] = win[it][2] = 0;
+            if (in_ok[it]) {   // uint8 HWC: 4 pixels x 3 channels = 12 contiguous bytes
+                const unsigned* pw = reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(Xv) +
+                                                                      (size_t)src * HI * HI * 3 + ((size_t)yin * HI + x0) * 3);
+                win[it][0] = pw[0]; win[it][1] = pw[1]; win[it][2] = pw[2];
+            }
+        }
+    }
+    V8 w2v = {};
+    if (tid < 9 * 64 / 8) w2v = reinterpret_cast<const V8*>(W2)[tid];
+    f32x4 pv[4] = {};
+    if (tid < 16) {
+        pv[0] = reinterpret_cast<const f32x4*>(b1)[tid];
+        pv[1] = reinterpret_cast<const f32x4*>(s1)[tid];
+        pv[2] = reinterpret_cast<const f32x4*>(b2)[tid];
+        pv[3] = reinterpret_cast<const f32x4*>(s2)[tid];
+    }
     // zero the activation image and the padding plane; planes 0-2 are written in full by the staging loop
     for (int i = tid; i < ES_BYTES / 16; i += NT) reinterpret_cast<f32x4*>(es)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = tid; i < NR * PW * 2 / 16; i += NT)
         reinterpret_cast<f32x4*>(lds + OFF_IN + 3 * NR * PW * 2)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < 9 * 64 / 8; i += NT) reinterpret_cast<V8*>(lds + OFF_W2)[i] = reinterpret_cast<const V8*>(W2)[i];
+    static_assert(9 * 64 / 8 <= NT, "one thread per 16-byte piece of the 3x3 weights");
+    if (tid < 9 * 64 / 8) reinterpret_cast<V8*>(lds + OFF_W2)[tid] = w2v;
     if (tid < 16) {
-        reinterpret_cast<f32x4*>(lds + OFF_B1)[tid] = reinterpret_cast<const f32x4*>(b1)[tid];
-        reinterpret_cast<f32x4*>(lds + OFF_S1)[tid] = reinterpret_cast<const f32x4*>(s1)[tid];
-        reinterpret_cast<f32x4*>(lds + OFF_B2)[tid] = reinterpret_cast<const f32x4*>(b2)[tid];
-        reinterpret_cast<f32x4*>(lds + OFF_S2)[tid] = reinterpret_cast<const f32x4*>(s2)[tid];
+        reinterpret_cast<f32x4*>(lds + OFF_B1)[tid] = pv[0];
+        reinterpret_cast<f32x4*>(lds + OFF_S1)[tid] = pv[1];
+        reinterpret_cast<f32x4*>(lds + OFF_B2)[tid] = pv[2];
+        reinterpret_cast<f32x4*>(lds + OFF_S2)[tid] = pv[3];
     }
-
-    // ---- stage the input band: column group g holds input columns 4(g-1) .. 4(g-1)+3 (g = 0 and g = NG-1 are padding)
-    if (!U8) {
-        const float* X = static_cast<const float*>(Xv) + (size_t)src * 3 * HI * HI;
-        for (int i = tid; i < 3 * NR * NG; i += NT) {
-            const int g = i % NG, cr = i / NG;           // cr = c * NR + ry
-            const int ry = cr % NR, c = cr / NR;
-            const int yin = rin0 + ry;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (g >= 1 && g <= 28 && yin >= 0 && yin < HI) {
-                const int x0 = flip ? 108 - 4 * (g - 1) : 4 * (g - 1);
-                v = *reinterpret_cast<const f32x4*>(X + ((size_t)c * HI + yin) * HI + x0);
-                if (flip) v = f32x4{v[3], v[2], v[1], v[0]};
-            }
+#pragma unroll
+    for (int it = 0; it < IN_IT; ++it) {
+        const int i = tid + it * NT;
+        if (i >= NIN) continue;
+        const int g = i % NG, cr = i / NG;
+        if (!U8) {
+            f32x4 v = vin[it];
+            if (flip) v = f32x4{v[3], v[2], v[1], v[0]};
             V4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
             *reinterpret_cast<V4*>(inp + cr * PW + 4 * g) = o;
-        }
-    } else {
-        // uint8 HWC: 4 pixels x 3 channels = 12 contiguous bytes; ToTensor (/255) then Normalize ((t - 0.5) / 0.5)
-        const unsigned char* X = static_cast<const unsigned char*>(Xv) + (size_t)src * HI * HI * 3;
-        for (int i = tid; i < NR * NG; i += NT) {
-            const int g = i % NG, ry = i / NG;
-            const int yin = rin0 + ry;
-            unsigned w0 = 0, w1 = 0, w2 = 0;
-            const bool ok = g >= 1 && g <= 28 && yin >= 0 && yin < HI;
-            if (ok) {
-                const int x0 = flip ? 108 - 4 * (g - 1) : 4 * (g - 1);
-                const unsigned* p = reinterpret_cast<const unsigned*>(X + ((size_t)yin * HI + x0) * 3);
-                w0 = p[0]; w1 = p[1]; w2 = p[2];
-            }
-            const unsigned long long lo = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
+        } else {
+            // ToTensor (/255) then Normalize ((t - 0.5) / 0.5)
+            const unsigned long long lo = (unsigned long long)win[it][0] | ((unsigned long long)win[it][1] << 32);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 V4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int byte = 3 * j + c;          // pixel j, channel c
-                    const unsigned u = byte < 8 ? (unsigned)(lo >> (8 * byte)) & 255u : (w2 >> (8 * (byte - 8))) & 255u;
-                    const float f = ok ? ((float)u / 255.0f - 0.5f) / 0.5f : 0.0f;
+                    const unsigned u = byte < 8 ? (unsigned)(lo >> (8 * byte)) & 255u : (win[it][2] >> (8 * (byte - 8))) & 255u;
+                    const float f = in_ok[it] ? ((float)u / 255.0f - 0.5f) / 0.5f : 0.0f;
                     o[flip ? 3 - j : j] = (T)f;
                 }
-                *reinterpret_cast<V4*>(inp + (c * NR + ry) * PW + 4 * g) = o;
+                *reinterpret_cast<V4*>(inp + (c * NR + cr) * PW + 4 * g) = o;
             }
         }
     }
