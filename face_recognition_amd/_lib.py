@@ -57,6 +57,7 @@ SIGNATURES = {
     "fb_threshold_score": (_I, [_P, _P, _P, _I, _D, _P]),
     "fb_destroy": (_I, [_P]),
     "ev_fold_scores": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "fa_align_warp": (_I, [_P, _I, _I, _P, _I, _P, _I, _I, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -190,6 +190,17 @@ int fb_destroy(fb_handle* h);
 int ev_fold_scores(float* fl, float* fr, const uint8_t* val_mask, int n_val, int P, int D, int method,
                    float* mu_scratch, float* scores_out, fra_stream stream);
 
+/* ---- face alignment warp ------------------------------------------------------------------------
+ * Mobilefacenet/utils/align_trans.py:50-52 (and :65-66 with a 96-wide crop):
+ *     cv2.warpAffine(img, M[:2], (W, H))[0:out_h, 0:out_w]        for every detected face
+ * frame: dev uint8 [H,W,3] (the BGR image as cv2 holds it).  matrices: dev f64 [n_faces][6], the
+ * forward 2x3 matrices M[:2] row-major, as transformation_from_points (:16-29) returns them.
+ * crops: dev uint8 [n_faces,out_h,out_w,3] -- with out_h = out_w = 112 exactly the batch
+ * mfn_forward_ex(input_format = 1) reads.  Bilinear, constant 0 border, OpenCV's 8-bit fixed-point
+ * arithmetic (1/32-pixel coordinates, 15-bit weights).  out_w must be a multiple of 4. */
+int fa_align_warp(const uint8_t* frame, int H, int W, const double* matrices, int n_faces, uint8_t* crops,
+                  int out_h, int out_w, fra_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

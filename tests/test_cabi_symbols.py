@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions():
     text = open(os.path.join(ROOT, "include", "face_recognition_amd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:fra|mfn|fb|ev)_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b((?:fra|mfn|fb|ev|fa)_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported_and_bound():

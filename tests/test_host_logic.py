@@ -155,3 +155,37 @@ def test_store_shard_overlap_arithmetic():
     assert ids.tolist() == [1, 2, 3, 4] and ids.dtype == np.int32
     with pytest.raises(RuntimeError):
         gs._as_ids([1, 2], 3)
+
+
+def test_alignment_matrices_equal_oracle_and_known_answers():
+    """align_trans.transformation_from_points (np.matrix form, as the reference writes it) against the
+    oracle's ndarray restatement and against transforms with a known answer."""
+    from face_recognition_amd import align_trans
+    from oracle import alignment_ref as ar
+    rng = np.random.default_rng(3)
+    T = np.asarray(ar.TEMPLATE_SQUARE)
+    ident = align_trans.alignment_matrices(np.concatenate([T[:, 0], T[:, 1]])[None])[0].reshape(2, 3)
+    assert np.allclose(ident, [[1, 0, 0], [0, 1, 0]], atol=1e-12)
+    for _ in range(20):
+        th, s, sh = rng.uniform(-1, 1), rng.uniform(0.3, 4), rng.uniform(-200, 900, 2)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        P = s * T @ R.T + sh                                   # exact similarity image of the template
+        lm = np.concatenate([P[:, 0], P[:, 1]])
+        M = align_trans.alignment_matrices(lm[None])[0].reshape(2, 3)
+        assert np.allclose(M, ar.landmarks_to_matrix(lm), rtol=0, atol=1e-9)
+        assert np.allclose(M[:, :2], R.T / s, atol=1e-9)       # the inverse similarity is recovered
+        assert np.allclose(P @ M[:, :2].T + M[:, 2], T, atol=1e-8)
+        noisy = lm + rng.normal(0, 2.0, 10)
+        assert np.allclose(align_trans.alignment_matrices(noisy[None])[0].reshape(2, 3), ar.landmarks_to_matrix(noisy), atol=1e-9)
+
+
+def test_alignment_oracle_warp_properties():
+    from oracle import alignment_ref as ar
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (150, 170, 3)).astype(np.uint8)
+    assert np.array_equal(ar.warp_affine(img, [[1, 0, -20.0], [0, 1, -30.0]]), img[30:142, 20:132])
+    out = ar.warp_affine(img, [[1, 0, 40.0], [0, 1, 0.0]])
+    assert (out[:, :40] == 0).all() and np.array_equal(out[:, 40:], img[:112, :72])
+    half = ar.warp_affine(img, [[1, 0, -0.5], [0, 1, 0.0]])   # half-pixel shift: rounded mean of two neighbours
+    want = (img[:112, :112].astype(int) + img[:112, 1:113].astype(int) + 1) >> 1
+    assert np.array_equal(half, want.astype(np.uint8))
