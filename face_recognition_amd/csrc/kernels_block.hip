@@ -9,9 +9,11 @@
 //      with the input tile's MFMA fragments held in registers for the whole kernel,
 //   2. writes PReLU(expand) as 16-bit values into an LDS image [row][x+1][64 ch] whose border
 //      columns and out-of-image rows stay zero (that IS the depthwise conv's zero padding),
-//   3. lets every lane build, for ITS output pixel, the 3x3 depthwise result of 8 channels from
-//      nine 16-byte LDS reads, and feeds those 8 values straight to the project MFMA as its B
-//      fragment -- the depthwise output never exists in memory at all.
+//   3. runs the 3x3 depthwise conv on the matrix cores as well: per 16-channel chunk and 16-pixel
+//      subtile five 16x16x32 MFMAs whose A operand carries the weights of two taps on its diagonal
+//      and whose B operand is one 16-byte unit of the LDS image per lane.  Bias enters as the C
+//      operand; after PReLU and rounding a lane's four values are its share of the project MFMA's
+//      B operand -- the depthwise output never exists in memory at all.
 // Project accumulators live in registers across slices.  The epilogue turns them into rows of
 // pixels through LDS so that the shortcut is read and the result written with contiguous 8-byte
 // pieces per lane.  The weight-matrix slices of the next 64 channels are fetched into registers
@@ -30,13 +32,11 @@
 // next to them.
 //
 // Channel order inside the expanded tensor: a lane of half h of the expand MFMA ends up with
-// channels 8q+4h+i (q<4, i<4) of each 32-channel tile, and the project MFMA wants, for k-step s,
-// element j of half h to be one fixed channel.  Taking channel 16s + 8(j>>2) + 4h + (j&3) makes
-// the two coincide, so a lane's 8 values per 16-channel group travel as ONE 16-byte unit from the
-// expand epilogue through LDS and the depthwise stage into the project MFMA.  Everything indexed
-// by expanded channel on the depthwise/project side (bias, slope, 3x3 weights, project weight
-// columns) is stored pre-permuted on the host: natural channel 16g + 8a + 4h + i sits at
-// position 16g + 8h + 4a + i.  The two slope arrays hold (PReLU slope - 1): prelu(v) = v + (slope-1) min(v,0).
+// channels 8q+4h+i (q<4, i<4) of each 32-channel tile; storing natural channel 16g + 8a + 4h + i at
+// position 16g + 8h + 4a + i lets it write them as 16-byte units.  Everything indexed by expanded
+// channel on the depthwise/project side (bias, slope, 3x3 weights, project weight columns) is
+// stored in that position order on the host.  The two slope arrays hold (PReLU slope - 1):
+// prelu(v) = v + (slope-1) min(v,0).
 #include <utility>
 
 #include "common.h"
@@ -59,22 +59,60 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 constexpr int cmin(int a, int b) { return a < b ? a : b; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-// ---- issue order of the depthwise stage (one slice = 4 k-steps s4 x 9 taps = 36 steps) ------------
-//   preamble : late header of s4 = 0 (project fragments a3[NT3], slopes s2a s2b), bias pair of
-//              s4 = 0, taps of steps 0 .. PD-1 (two reads each: image unit, 3x3 weights)
-//   step i   : taps of step i + PD; if i % 9 == 4 the bias pair of the next s4;  WAIT for step i;
-//              8 FMAs; if i % 9 == 8: PReLU, project MFMAs, then the late header of the next s4
-// dw_ahead(i) = reads issued after the taps of step i and before its wait.
-constexpr int DW_STEPS = 36, DW_PD = 3, DW_RING = DW_PD + 1;
-constexpr int dw_ahead(int step, int nt3) {
-    int n = 2 * (cmin(step + DW_PD, DW_STEPS - 1) - step);
-    for (int j = 4; j < DW_STEPS - 9; j += 9)          // bias pairs go out in steps 4, 13, 22
-        if (j <= step && j >= step - DW_PD) n += 2;
-    for (int e = 8; e < DW_STEPS - 9; e += 9)          // late headers after steps 8, 17, 26
-        if (e < step && e >= step - DW_PD) n += nt3 + 2;
-    return cmin(n, 15);
+// ---- issue order of the depthwise + project stage -------------------------------------------------
+// A slice (64 expanded channels) is four 16-channel chunks q; a chunk's depthwise conv is five
+// 16x16x32 MFMAs (step p = one tap pair of dw_tap(); the tenth tap has zero weights) per 16-pixel subtile,
+// two subtiles per wave: step ST = 5 q + p, 20 steps.  LDS reads in issue order:
+//   preamble : bias(0), slope(0), w16(0)[0..4], taps(0), taps(1)          (taps = one read per subtile)
+//   step ST  : taps(ST + PD); if q odd and p == 2 the first min(4, NT16) project fragments of the pair;
+//              WAIT for taps(ST); w16(q+1)[p]; after the MFMAs of p == 0: bias(q+1);
+//              at p == 4 after the PReLU: slope(q+1), then for q odd the project loop
+//              { WAIT fragment n; two MFMAs; issue fragment n + 4 }.
+// dw_outstanding() replays that order and returns the number of reads issued after the awaited one.
+#ifndef DW_PD_VALUE
+#define DW_PD_VALUE 2
+#endif
+constexpr int DW_STEPS = 20, DW_PD = DW_PD_VALUE, DW_RING = DW_PD + 1;
+constexpr int dw_outstanding(int nt16, int kind, int st, int n) {   // kind 0: taps(st); kind 1: fragment n in step st
+    int issued = 7;
+    int taps_idx[DW_STEPS] = {};
+    int a3_idx[64] = {};
+    for (int i = 0; i < DW_PD; ++i) { issued += 2; taps_idx[i] = issued - 1; }
+    for (int ST = 0; ST < DW_STEPS; ++ST) {
+        const int q = ST / 5, p = ST % 5;
+        if (ST + DW_PD < DW_STEPS) { issued += 2; taps_idx[ST + DW_PD] = issued - 1; }
+        if ((q & 1) && p == 2)
+            for (int i = 0; i < cmin(4, nt16); ++i) { issued += 1; a3_idx[i] = issued - 1; }
+        if (kind == 0 && st == ST) return cmin(issued - 1 - taps_idx[ST], 15);
+        if (q + 1 < 4) issued += 1;                       // w16 of the next chunk
+        if (p == 0 && q + 1 < 4) issued += 1;             // bias of the next chunk
+        if (p == 4) {
+            if (q + 1 < 4) issued += 1;                   // slope of the next chunk
+            if (q & 1)
+                for (int i = 0; i < nt16; ++i) {
+                    if (kind == 1 && st == ST && n == i) return cmin(issued - 1 - a3_idx[i], 15);
+                    if (i + 4 < nt16) { issued += 1; a3_idx[i + 4] = issued - 1; }
+                }
+        }
+    }
+    return 0;
 }
 
+// tap pairs of the five depthwise MFMAs: (0,1) (3,4) (6,7) are horizontal neighbours, (2,5) vertical ones, the
+// last is tap 8 with the zero tap 9.  A ds_read_b128 is served in groups of 16 lanes that mix the two
+// k-groups g = 0,1 (and 2,3), so those two read the two TAPS of a pair at one 16-byte unit: the slots of a
+// group then differ by 0/1 (stride 1) or an odd number (stride 2) and keep their distinct banks.
+constexpr int dw_tap(int p, int half) {
+    constexpr int t[5][2] = {{0, 1}, {3, 4}, {6, 7}, {2, 5}, {8, 11}};
+    return t[p][half];
+}
+#define LDS_READ_U16(dst, addr, off) asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+
+template <int H, int S> constexpr int block_pitch() {
+    return S == 2 ? (H >= 28 ? ((H + 2) | 1) : H + 2) : (H >= 14 ? (H + 2 + 15) / 16 * 16 : H + 2);
+}
 
 // ---- expand stage: LDS reads of one 32-channel tile nt, in issue order: bias quads bq[4], fragments
 // w1[KS1], slope quads sl[4]; the first pixel tile waits with counts, later tiles find the data there ----
@@ -123,76 +161,115 @@ template <typename T, int KS1, int CEXP, int PW1> struct ExpStage {
     }
 };
 
-// ---- depthwise + project stage of one slice (see the issue order above dw_ahead) ------------------
-template <typename T, int CEXP, int NT3, int PW3> struct DwStage {
+// ---- depthwise + project stage of one slice on the matrix cores (issue order above) -----------------
+// Depthwise conv as D[ch][px] = sum over (tap, ch') of Diag[ch][(tap, ch')] . E[(tap, ch')][px]: the A
+// operand of a 16x16x32 MFMA holds the weights of two taps on the diagonal (lane (m = l & 15, g = l >> 4):
+// k = 8 g + j is tap dw_tap(p, g & 1), channel 8 (g >> 1) + j, non-zero only where that channel is m), the
+// B operand is one 16-byte unit of the LDS image per lane.  The 72 multiply-adds per 8 channels and pixel
+// leave the vector ALU; a lane ends up with channels 4g .. 4g+3 of the chunk for its pixel, which after
+// bias (the MFMA's C operand), PReLU and rounding IS its half of the project MFMA's B operand for the
+// chunk pair (k = 8 g + j: j < 4 from the even chunk, j >= 4 from the odd one; the project weights are
+// stored in that order when their slice is staged).
+template <typename T, int CEXP, int NT16, int PW3, int ST1> struct DwStage {
     typedef typename vec8<T>::type V8;
-    V8 er[DW_RING], wr[DW_RING];   // ring: image unit and 3x3 weights of a tap
-    V8 a3[NT3];                    // project fragments of the current k-step
-    f32x4 s2a, s2b, b2[2][2];
-    float d[8];
-    int tapb[9];   // LDS address of unit h of this lane's 9 taps; + 32 s4
-    int w2l;       // 3x3 weights of the slice for half h; + tap CEXP*2 + 32 s4
-    int pb;        // depthwise bias quads of the slice for half h; + 64 s4 (+16); slopes CEXP*4 further
-    int w3l;       // this lane's W3 row (+ 16 h); + 32 n3 PW3 + 32 s4
+    V8 er[DW_RING][2];             // ring: image unit of a tap pair, per subtile
+    V8 a3[4];                      // ring: project fragments
+    uint32_t w16[5];               // this lane's depthwise weight of each tap pair (16 bits)
+    uint32_t msk[4];               // where that weight sits inside the diagonal fragment (all zero for half the lanes)
+    f32x4 bias, slope;
+    f32x4 acc[2];
+    V8 bf[2];                      // project B operand of the chunk pair, per subtile
+    int tb[5];                     // LDS address of this lane's unit for tap pair p in subtile 0; + ST1 for subtile 1; + 32 q
+    int w2l[2];                    // this lane's 3x3 weight: [0] tap 0 or 1 (pairs 0..2), [1] tap 2 or 5 (pairs 3, 4); + tap offset + 32 q
+    int pb;                        // depthwise bias quad of channels 4g..; + 64 q; slopes CEXP*4 further
+    int w3l;                       // this lane's project weight row 16 (g & 1) + m, unit g >> 1; + 32 n PW3 + 32 pair
 
-    template <int ST> __device__ __forceinline__ void issue_tap() {
-        constexpr int s4 = ST / 9, k = ST % 9;
-        LDS_READ16(er[ST % DW_RING], tapb[k], 32 * s4);
-        LDS_READ16(wr[ST % DW_RING], w2l, k * CEXP * 2 + 32 * s4);
+    template <int ST> __device__ __forceinline__ void issue_taps() {
+        constexpr int q = ST / 5, p = ST % 5;
+        LDS_READ16(er[ST % DW_RING][0], tb[p], 32 * q);
+        LDS_READ16(er[ST % DW_RING][1], tb[p], ST1 + 32 * q);
     }
-    template <int S4, int N3 = 0> __device__ __forceinline__ void issue_late() {
-        if constexpr (N3 < NT3) {
-            LDS_READ16(a3[N3], w3l, N3 * 32 * PW3 + 32 * S4);
-            issue_late<S4, N3 + 1>();
-        } else {
-            LDS_READ16(s2a, pb, CEXP * 4 + 64 * S4);
-            LDS_READ16(s2b, pb, CEXP * 4 + 64 * S4 + 16);
+    template <int Q, int P> __device__ __forceinline__ void issue_w16() {
+        // pairs 0..2: taps 3 P (+1 for the odd half); pair 3: taps 2 / 5; pair 4: six rows further, tap 8 / the zero row 11
+        if constexpr (P < 3) LDS_READ_U16(w16[P], w2l[0], 3 * P * (CEXP * 2 + 32) + 32 * Q);
+        else LDS_READ_U16(w16[P], w2l[1], (P - 3) * 6 * (CEXP * 2 + 32) + 32 * Q);
+    }
+    template <int Q> __device__ __forceinline__ void issue_bias() { LDS_READ16(bias, pb, 64 * Q); }
+    template <int Q> __device__ __forceinline__ void issue_slope() { LDS_READ16(slope, pb, CEXP * 4 + 64 * Q); }
+    template <int PAIR, int N> __device__ __forceinline__ void issue_a3() { LDS_READ16(a3[N & 3], w3l, N * 32 * PW3 + 32 * PAIR); }
+    template <int PAIR, int N = 0> __device__ __forceinline__ void issue_a3_first() {
+        if constexpr (N < cmin(4, NT16)) { issue_a3<PAIR, N>(); issue_a3_first<PAIR, N + 1>(); }
+    }
+    __device__ __forceinline__ void preamble() {
+        issue_bias<0>();
+        issue_slope<0>();
+        issue_w16<0, 0>(); issue_w16<0, 1>(); issue_w16<0, 2>(); issue_w16<0, 3>(); issue_w16<0, 4>();
+        preamble_taps<0>();
+    }
+    template <int ST> __device__ __forceinline__ void preamble_taps() {
+        if constexpr (ST < DW_PD) { issue_taps<ST>(); preamble_taps<ST + 1>(); }
+    }
+    template <int ST, int PAIR, int N = 0> __device__ __forceinline__ void project(f32x4 (&pacc)[2][NT16]) {
+        if constexpr (N < NT16) {
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a3[N & 3]) : "n"(dw_outstanding(NT16, 1, ST, N)));
+            pacc[0][N] = mfma16(a3[N & 3], bf[0], pacc[0][N]);
+            pacc[1][N] = mfma16(a3[N & 3], bf[1], pacc[1][N]);
+            if constexpr (N + 4 < NT16) {
+                __builtin_amdgcn_sched_barrier(0);         // the ring slot is free once both MFMAs are issued
+                issue_a3<PAIR, N + 4>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            project<ST, PAIR, N + 1>(pacc);
         }
     }
-    template <int S4> __device__ __forceinline__ void issue_bias() {
-        LDS_READ16(b2[S4 & 1][0], pb, 64 * S4);
-        LDS_READ16(b2[S4 & 1][1], pb, 64 * S4 + 16);
-    }
-    template <int ST = 0> __device__ __forceinline__ void preamble() {
-        if constexpr (ST == 0) { issue_late<0>(); issue_bias<0>(); }
-        if constexpr (ST < DW_PD) { issue_tap<ST>(); preamble<ST + 1>(); }
-    }
-    template <int N3 = 0> __device__ __forceinline__ void pin_late() {
-        if constexpr (N3 < NT3) { asm volatile("" : "+v"(a3[N3])); pin_late<N3 + 1>(); }
-        else asm volatile("" : "+v"(s2a), "+v"(s2b));
-    }
-    template <int ST = 0> __device__ __forceinline__ void run(f32x16 (&pacc)[NT3]) {
+    template <int ST = 0> __device__ __forceinline__ void run(f32x4 (&pacc)[2][NT16]) {
         if constexpr (ST < DW_STEPS) {
-            constexpr int s4 = ST / 9, k = ST % 9, slot = ST % DW_RING;
-            if constexpr (ST + DW_PD < DW_STEPS) issue_tap<ST + DW_PD>();
-            if constexpr (k == 4 && s4 + 1 < 4) issue_bias<s4 + 1>();
-            if constexpr (k == 0) {
-                // the bias pair went out before this step's taps, so it has arrived with them
-                asm volatile("s_waitcnt lgkmcnt(%4)"
-                             : "+v"(er[slot]), "+v"(wr[slot]), "+v"(b2[s4 & 1][0]), "+v"(b2[s4 & 1][1])
-                             : "n"(dw_ahead(ST, NT3)));
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    d[j] = fmaf((float)er[slot][j], (float)wr[slot][j], b2[s4 & 1][j >> 2][j & 3]);
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(er[slot]), "+v"(wr[slot]) : "n"(dw_ahead(ST, NT3)));
-#pragma unroll
-                for (int j = 0; j < 8; ++j) d[j] = fmaf((float)er[slot][j], (float)wr[slot][j], d[j]);
+            constexpr int q = ST / 5, p = ST % 5, slot = ST % DW_RING;
+            if constexpr (ST + DW_PD < DW_STEPS) issue_taps<ST + DW_PD>();
+            if constexpr ((q & 1) && p == 2) issue_a3_first<(q >> 1)>();
+            // everything issued before taps(ST) has landed with them: w16[p], bias (p == 0), slope (p == 4)
+            if constexpr (p == 0)
+                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(er[slot][0]), "+v"(er[slot][1]), "+v"(w16[p]), "+v"(bias)
+                             : "n"(dw_outstanding(NT16, 0, ST, 0)));
+            else if constexpr (p == 4)
+                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(er[slot][0]), "+v"(er[slot][1]), "+v"(w16[p]), "+v"(slope)
+                             : "n"(dw_outstanding(NT16, 0, ST, 0)));
+            else
+                asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(er[slot][0]), "+v"(er[slot][1]), "+v"(w16[p])
+                             : "n"(dw_outstanding(NT16, 0, ST, 0)));
+            const uint32_t wd = w16[p] | (w16[p] << 16);
+            const u32x4 du = {wd & msk[0], wd & msk[1], wd & msk[2], wd & msk[3]};
+            const V8 dg = __builtin_bit_cast(V8, du);
+            if constexpr (q + 1 < 4) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_w16<q + 1, p>();
             }
-            if constexpr (k == 8) {
-                // the late header went out before this k-step's tap PD, so it arrived before tap 8 did
-                pin_late();
-                V8 bf;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    bf[j] = (T)fmaf(fminf(d[j], 0.0f), s2a[j], d[j]);               // PReLU: s2 = slope - 1
-                    bf[4 + j] = (T)fmaf(fminf(d[4 + j], 0.0f), s2b[j], d[4 + j]);
+            if constexpr (p == 0) {
+                acc[0] = mfma16(dg, er[slot][0], bias);
+                acc[1] = mfma16(dg, er[slot][1], bias);
+                if constexpr (q + 1 < 4) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_bias<q + 1>();
                 }
+            } else {
+                acc[0] = mfma16(dg, er[slot][0], acc[0]);
+                acc[1] = mfma16(dg, er[slot][1], acc[1]);
+            }
+            if constexpr (p == 4) {
 #pragma unroll
-                for (int n3 = 0; n3 < NT3; ++n3) pacc[n3] = mfma32(a3[n3], bf, pacc[n3]);
-                if constexpr (s4 + 1 < 4) {
-                    __builtin_amdgcn_sched_barrier(0);     // the header registers are free once the MFMAs are issued
-                    issue_late<s4 + 1>();
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float d = acc[s][i];
+                        bf[s][4 * (q & 1) + i] = (T)fmaf(fminf(d, 0.0f), slope[i], d);   // PReLU: slope holds slope - 1
+                    }
+                if constexpr (q + 1 < 4) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_slope<q + 1>();
+                }
+                if constexpr (q & 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    project<ST, (q >> 1)>(pacc);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -221,17 +298,22 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     // would skip the two border slots at every row end and put two lanes on one bank.
     constexpr int POW = Wo <= 8 ? 8 : (Wo <= 16 ? 16 : 32), RPT = 32 / POW;
     constexpr int MTI = (PIN + 31) / 32, MTO = (TR + RPT - 1) / RPT;
-    constexpr int KS1 = CIN / 16, NT3 = COUT / 32, NCH = CEXP / 64;
-    constexpr int PITCH = W + 2;                           // pixel slots per LDS row (zero border each side)
+    constexpr int KS1 = CIN / 16, NT16 = COUT / 16, NCH = CEXP / 64;
+    // pixel slots per LDS row (zero border each side).  The depthwise reads of a 16-lane group stay on distinct
+    // banks when vertically neighbouring taps are a multiple of 16 slots apart (stride 1) or an odd number (stride 2)
+    constexpr int PITCH = block_pitch<H, S>();
     constexpr int SLOT = 144;                              // bytes per pixel slot: 64 channels + one unit of padding
-    constexpr int PW1 = CIN * 2 + 16, PW3 = 144;           // padded row pitch of the W1 / W3 slices
+    // padded row pitch of the W1 slice; the W3 slice is stored as rows of 64 + 16 bytes: row 32 n + 16 (g & 1) + m
+    // holds, for output channel 16 n + m, the units [pair][g >> 1] of k-group g (see store_w)
+    constexpr int PW1 = CIN * 2 + 16, PW3 = 80;
     constexpr int ES_BYTES = RIN * PITCH * SLOT;
-    constexpr int W1_BYTES = 64 * PW1, W3_BYTES = COUT * PW3;
+    constexpr int W1_BYTES = 64 * PW1, W3_BYTES = 2 * COUT * PW3;
     constexpr int NWB = MODE >= 1 ? 2 : 1;                 // LDS copies of each weight slice
     constexpr int OFF_W1 = ES_BYTES, OFF_W3 = OFF_W1 + NWB * W1_BYTES, OFF_PAR = OFF_W3 + NWB * W3_BYTES;
     constexpr int OFF_B1 = OFF_PAR, OFF_S1 = OFF_B1 + CEXP * 4, OFF_B2 = OFF_S1 + CEXP * 4, OFF_S2 = OFF_B2 + CEXP * 4,
                   OFF_W2 = OFF_S2 + CEXP * 4;
-    constexpr int MAIN_BYTES = OFF_W2 + 9 * CEXP * 2;
+    constexpr int PW2 = CEXP * 2 + 32;                     // 3x3 weight rows, padded so that the two taps of a pair sit on different banks
+    constexpr int MAIN_BYTES = OFF_W2 + 12 * PW2;     // nine taps, then zeros: "tap 11" is the odd half of the last tap pair
     constexpr int P32 = COUT * 4 + 16;                     // epilogue staging: f32 pixel rows, padded
     constexpr int EPI_BYTES = POUT * P32;                  // overlays the image and weight buffers
     constexpr int LDS_BYTES = cmax(MAIN_BYTES, EPI_BYTES);
@@ -279,7 +361,16 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 #pragma unroll
         for (int i = 0; i < W3_PT; ++i) {
             const int v = tid + i * NT;
-            if (v < W3_V) *reinterpret_cast<V8*>(lds + OFF_W3 + buf * W3_BYTES + (v >> 3) * PW3 + (v & 7) * 16) = wreg3[i];
+            // vector u = 4 P + t of row `co` holds positions 32 P + 8 t ..: its low half is the (t >> 1) half of
+            // k-group g = 2 (t & 1) of pair P, its high half that of g + 1.  The two k-groups a read group mixes
+            // (g even / odd) go to different ROWS at the same unit, which keeps the fragment reads conflict free.
+            if (v < W3_V) {
+                const int co = v >> 3, u = v & 7, t = u & 3;
+                char* dst = lds + OFF_W3 + buf * W3_BYTES + (32 * (co >> 4) + (co & 15)) * PW3 + (2 * (u >> 2) + (t & 1)) * 16 + (t >> 1) * 8;
+                const u32x4 w = __builtin_bit_cast(u32x4, wreg3[i]);
+                *reinterpret_cast<uint2*>(dst) = uint2{w[0], w[1]};
+                *reinterpret_cast<uint2*>(dst + 16 * PW3) = uint2{w[2], w[3]};
+            }
         }
     };
     fetch_w(0);
@@ -291,8 +382,11 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         reinterpret_cast<f32x4*>(lds + OFF_B2)[i] = reinterpret_cast<const f32x4*>(b2p)[i];
         reinterpret_cast<f32x4*>(lds + OFF_S2)[i] = reinterpret_cast<const f32x4*>(s2p)[i];
     }
-    for (int i = tid; i < 9 * CEXP / 8; i += NT)
-        reinterpret_cast<V8*>(lds + OFF_W2)[i] = reinterpret_cast<const V8*>(W2p)[i];
+    for (int i = tid; i < 12 * CEXP / 8; i += NT) {
+        const int row = i / (CEXP / 8), col = i - row * (CEXP / 8);
+        *reinterpret_cast<u32x4*>(lds + OFF_W2 + row * PW2 + col * 16) =
+            row < 9 ? reinterpret_cast<const u32x4*>(W2p)[i] : u32x4{0u, 0u, 0u, 0u};
+    }
 
     // ---- input fragments (B operand of the expand GEMM), resident while an image's slices are expanded -------
     V8 xf[MTIW][KS1];
@@ -316,21 +410,44 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     };
     load_x(blockIdx.y);
 
-    // ---- output pixel of this lane: LDS byte address of unit h of each of its 9 taps ----------
-    int tapb[9];
-    const int oy = wave * RPT + r / POW, ox = r % POW;     // this lane's output pixel inside the band
-    const bool out_ok = (ox < Wo) && (oy < TR);
-    const int po = oy * Wo + ox;
-    {
-        const int cy = out_ok ? oy : 0, cx = out_ok ? ox : 0;
+    // ---- output pixels of this lane on the depthwise / project side: pixel m of each 16-pixel subtile ----------
+    const int m16 = lane & 15, g4 = lane >> 4;
+    // Subtile 1 holds the pixels 16 lanes further on in the tile: 16 columns further (one tile row of 32), the next
+    // row (16) or two rows further (8), always a fixed number of bytes after subtile 0's.  Lanes without an
+    // output pixel still read -- their own (unused) column and row, so that the 16 lanes of a read group keep
+    // distinct banks; past the end of a row that is the next row, past the last row the weight buffers.
+    // Whatever such a lane reads stays in ITS column of the MFMA results (a pixel is a column of both the
+    // depthwise and the project product), and that column is never stored.
+    constexpr int ST1 = POW == 32 ? 16 * S * SLOT : (16 / POW) * S * PITCH * SLOT;
+    static_assert(ST1 + 96 < 65536, "subtile offset must fit the instruction's offset field");
+    int tb[5];            // LDS byte address of unit (g >> 1) of tap dw_tap(p, g & 1) (tap 11 -> tap 7, its weights are zero)
+    bool out_ok[2];
+    int po[2];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) tapb[ky * 3 + kx] = ((cy * S + ky) * PITCH + cx * S + kx) * SLOT + 16 * h;
+    for (int st = 0; st < 2; ++st) {
+        const int rr = 16 * st + m16;
+        const int oy = wave * RPT + rr / POW, ox = rr % POW;
+        out_ok[st] = (ox < Wo) && (oy < TR);
+        po[st] = oy * Wo + ox;
     }
+    {
+        const int oy = wave * RPT + m16 / POW, ox = m16 % POW;
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            const int t9 = (g4 & 1) ? dw_tap(p, 1) : dw_tap(p, 0);
+            const int tap = t9 > 8 ? 7 : t9;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            tb[p] = ((oy * S + ky) * PITCH + ox * S + kx) * SLOT + 16 * (g4 >> 1);
+        }
+    }
+    // diagonal fragment: element j of register pair j >> 1 is non-zero where channel 8 (g >> 1) + j is this lane's row
+    uint32_t dmask[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        dmask[i] = ((m16 >> 3) == (g4 >> 1) && ((m16 & 7) >> 1) == i) ? ((m16 & 1) ? 0xFFFF0000u : 0x0000FFFFu) : 0u;
 
-    // project accumulators: row acc_row(g,h) of tile n3 <-> channel 32 n3 + 8q + 4h + i; the bias joins in the epilogue
-    f32x16 pacc[NT3];
+    // project accumulators: tile n of subtile st, register i <-> output channel 16 n + 4 g + i; the bias joins in the epilogue
+    f32x4 pacc[2][NT16];
 
     // ================= expand of slice c: E[64 ch][pixels] = PReLU(W1 . X + b1) -> LDS image =================
     typedef ExpStage<T, KS1, CEXP, PW1> Ex;
@@ -377,14 +494,23 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     // ================= depthwise 3x3 of slice c from the LDS image -> project MFMA =================================
     auto dwproject = [&](int c, int wb, int eb) {
         if (wave >= MTO) return;                           // wave-uniform
-        DwStage<T, CEXP, NT3, PW3> dw;
+        DwStage<T, CEXP, NT16, PW3, ST1> dw;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) dw.tapb[k] = tapb[k] + eb * ES_BYTES;
-        dw.w2l = OFF_W2 + 128 * c + 16 * h;
-        dw.pb = OFF_B2 + 256 * c + 32 * h;
-        dw.w3l = OFF_W3 + wb * W3_BYTES + r * PW3 + 16 * h;
+        for (int p = 0; p < 5; ++p) dw.tb[p] = tb[p] + eb * ES_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dw.msk[i] = dmask[i];
+        dw.w2l[0] = OFF_W2 + (g4 & 1) * PW2 + (64 * c + m16) * 2;
+        dw.w2l[1] = OFF_W2 + (2 + 3 * (g4 & 1)) * PW2 + (64 * c + m16) * 2;
+        dw.pb = OFF_B2 + 256 * c + 16 * g4;
+        dw.w3l = OFF_W3 + wb * W3_BYTES + (16 * (g4 & 1) + m16) * PW3 + 16 * (g4 >> 1);
+#ifdef DW_YOUNG_PRIO
+        if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);   // the later-dispatched wave of a SIMD otherwise loses every arbitration
+#endif
         dw.preamble();
         dw.run(pacc);
+#ifdef DW_YOUNG_PRIO
+        if (wave >= NW / 2) __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     // A workgroup keeps its band and walks over images blockIdx.y, blockIdx.y + gridDim.y, ...: the per-channel
@@ -400,9 +526,9 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         fetch_w(1);
         __syncthreads();
 #pragma unroll
-        for (int n3 = 0; n3 < NT3; ++n3)
+        for (int st = 0; st < 2; ++st)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) pacc[n3][g] = 0.0f;
+            for (int n = 0; n < NT16; ++n) pacc[st][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (MODE == 1) {
             // expand | barrier | depthwise+project, next slice's weights into the other buffer | barrier
 #pragma unroll 1
@@ -438,14 +564,14 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         }
 
         // ---- epilogue: accumulators -> f32 pixel rows in LDS -> (+ bias, + shortcut) -> NHWC, 8 bytes per lane -------
-        if (wave < MTO && out_ok) {
-            char* dst = lds + po * P32 + 16 * h;
+        if (wave < MTO) {
     #pragma unroll
-            for (int n3 = 0; n3 < NT3; ++n3)
+            for (int st = 0; st < 2; ++st)
+                if (out_ok[st]) {
+                    char* dst = lds + po[st] * P32 + 16 * g4;
     #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<f32x4*>(dst + (32 * n3 + 8 * q) * 4) =
-                        f32x4{pacc[n3][4 * q], pacc[n3][4 * q + 1], pacc[n3][4 * q + 2], pacc[n3][4 * q + 3]};
+                    for (int n = 0; n < NT16; ++n) *reinterpret_cast<f32x4*>(dst + 64 * n) = pacc[st][n];
+                }
         }
         __syncthreads();
         {
@@ -478,8 +604,8 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 template <int CIN, int CEXP, int COUT, int H, int S, int TR, int MODE>
 constexpr int block_lds_bytes() {
     constexpr int RIN = (S == 1) ? TR + 2 : 2 * TR + 1;
-    constexpr int main_bytes = RIN * (H + 2) * 144 +
-                               (MODE >= 1 ? 2 : 1) * (64 * (CIN * 2 + 16) + COUT * 144) + 4 * CEXP * 4 + 9 * CEXP * 2;
+    constexpr int main_bytes = RIN * block_pitch<H, S>() * 144 +
+                               (MODE >= 1 ? 2 : 1) * (64 * (CIN * 2 + 16) + COUT * 160) + 4 * CEXP * 4 + 12 * (CEXP * 2 + 32);
     constexpr int epi_bytes = TR * (H / S) * (COUT * 4 + 16);
     return cmax(main_bytes, epi_bytes);
 }
