@@ -37,6 +37,9 @@ __device__ __forceinline__ f32x4 mfma16(vec8<f16>::type a, vec8<f16>::type b, f3
 __device__ __forceinline__ f32x4 mfma16(vec8<bf16>::type a, vec8<bf16>::type b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// min(v, 0) as ONE instruction: the median of (v, 0, a huge negative number).  fminf() costs two (IEEE minimum
+// first quietens a signalling NaN with a v_max v, v); activations here are finite and far above -3e38.
+__device__ __forceinline__ float neg_part(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, -3.0e38f); }
 __device__ __forceinline__ int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 
 // ---- error plumbing -------------------------------------------------------------------------

@@ -261,7 +261,7 @@ template <typename T, int CEXP, int NT16, int PW3, int ST1> struct DwStage {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float d = acc[s][i];
-                        bf[s][4 * (q & 1) + i] = (T)fmaf(fminf(d, 0.0f), slope[i], d);   // PReLU: slope holds slope - 1
+                        bf[s][4 * (q & 1) + i] = (T)fmaf(neg_part(d), slope[i], d);   // PReLU: slope holds slope - 1
                     }
                 if constexpr (q + 1 < 4) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -465,7 +465,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float v = acc[4 * q + i];
-                        o[4 * a + i] = (T)fmaf(fminf(v, 0.0f), ex.sl[q][i], v);   // PReLU: sl = slope - 1
+                        o[4 * a + i] = (T)fmaf(neg_part(v), ex.sl[q][i], v);   // PReLU: sl = slope - 1
                     }
                 }
                 // 16-byte unit (2 nt + s2) * 2 + h of the slot

@@ -74,8 +74,8 @@ template <typename T, int TR> struct StemDwStage {
                 V8 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    o[j] = (T)fmaf(fminf(d[j], 0.0f), s2a[j], d[j]);                  // PReLU: s2 = slope - 1
-                    o[4 + j] = (T)fmaf(fminf(d[4 + j], 0.0f), s2b[j], d[4 + j]);
+                    o[j] = (T)fmaf(neg_part(d[j]), s2a[j], d[j]);                  // PReLU: s2 = slope - 1
+                    o[4 + j] = (T)fmaf(neg_part(d[4 + j]), s2b[j], d[4 + j]);
                 }
                 *reinterpret_cast<V8*>(out + (size_t)row * 56 * 64) = o;
             }
@@ -258,7 +258,7 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, const T* __restrict__
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const float v = acc[4 * (2 * g + a) + i];
-                            o[4 * a + i] = (T)fmaf(fminf(v, 0.0f), sl[i], v);   // PReLU: sl = slope - 1
+                            o[4 * a + i] = (T)fmaf(neg_part(v), sl[i], v);   // PReLU: sl = slope - 1
                         }
                     }
                     const int u = 4 * m + 2 * g + h;       // channels [8u, 8u+8)
