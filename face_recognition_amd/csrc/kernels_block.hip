@@ -564,6 +564,28 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         }
 
         // ---- epilogue: accumulators -> f32 pixel rows in LDS -> (+ bias, + shortcut) -> NHWC, 8 bytes per lane -------
+        // A thread's units (4 channels of one pixel) are NT apart, i.e. a fixed number of pixels: one base address each
+        // for the shortcut, the staging rows and the output, everything else is a compile-time offset.  The shortcut
+        // values are requested a chunk of EPI_CH units ahead, the first chunk before the accumulators are staged, so
+        // their latency runs under the staging pass, its barrier and the previous chunk's stores.
+        constexpr int G = COUT / 4, UNITS = POUT * G;
+        constexpr int EPI_IT = (UNITS + NT - 1) / NT, EPI_CH = 4, EPI_NCH = (EPI_IT + EPI_CH - 1) / EPI_CH;
+        constexpr int PSTEP = NT / G;                          // pixels between two units of a thread
+        const int g = tid % G, p0 = tid / G;
+        const size_t pix0 = (size_t)img * Ho * Wo + (size_t)y0 * Wo;
+        const T* xs = X + (pix0 + p0) * CIN + 4 * g;          // only dereferenced when RESID
+        V4 rr[2][EPI_CH];
+        auto fetch_shortcut = [&](auto chunk) {
+            constexpr int k = decltype(chunk)::value;
+            if constexpr (RESID && k < EPI_NCH) {
+    #pragma unroll
+                for (int j = 0; j < EPI_CH; ++j) {
+                    const int it = k * EPI_CH + j;
+                    if (it < EPI_IT && p0 + it * PSTEP < POUT) rr[k & 1][j] = *reinterpret_cast<const V4*>(xs + (size_t)it * PSTEP * CIN);
+                }
+            }
+        };
+        fetch_shortcut(std::integral_constant<int, 0>{});
         if (wave < MTO) {
     #pragma unroll
             for (int st = 0; st < 2; ++st)
@@ -575,26 +597,28 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         }
         __syncthreads();
         {
-            constexpr int G = COUT / 4, UNITS = POUT * G;      // a unit = 4 channels of one pixel
-            const int g = tid % G;
             const f32x4 bias = *reinterpret_cast<const f32x4*>(b3 + 4 * g);
-            const size_t pix0 = (size_t)img * Ho * Wo + (size_t)y0 * Wo;
-            const T* Xo = X + pix0 * CIN;
-            T* Oo = O + pix0 * COUT;
-    #pragma unroll 4
-            for (int u = tid; u < UNITS; u += NT) {
-                const int p = u / G;
-                f32x4 v = *reinterpret_cast<const f32x4*>(lds + p * P32 + g * 16);
-                if (RESID) {
-                    const V4 rr = *reinterpret_cast<const V4*>(Xo + (size_t)p * CIN + 4 * g);
+            T* os = O + (pix0 + p0) * COUT + 4 * g;
+            const char* ls = lds + p0 * P32 + g * 16;
+            static_for<EPI_NCH>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                fetch_shortcut(std::integral_constant<int, k + 1>{});
     #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)rr[i];
+                for (int j = 0; j < EPI_CH; ++j) {
+                    const int it = k * EPI_CH + j;
+                    if (it < EPI_IT && p0 + it * PSTEP < POUT) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(ls + it * PSTEP * P32);
+                        if (RESID) {
+    #pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] += (float)rr[k & 1][j][i];
+                        }
+                        V4 o;
+    #pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = (T)(v[i] + bias[i]);
+                        *reinterpret_cast<V4*>(os + (size_t)it * PSTEP * COUT) = o;
+                    }
                 }
-                V4 o;
-    #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (T)(v[i] + bias[i]);
-                *reinterpret_cast<V4*>(Oo + (size_t)p * COUT + 4 * g) = o;
-            }
+            });
         }
         if (has_next) __syncthreads();   // staging reads are done before the region is zeroed and restaged
     }
