@@ -98,12 +98,13 @@ constexpr int dw_outstanding(int nt16, int kind, int st, int n) {   // kind 0: t
     return 0;
 }
 
-// tap pairs of the five depthwise MFMAs: (0,1) (3,4) (6,7) are horizontal neighbours, (2,5) vertical ones, the
-// last is tap 8 with the zero tap 9.  A ds_read_b128 is served in groups of 16 lanes that mix the two
+// tap pairs of the five depthwise MFMAs: (0,1) (3,4) (6,7) are horizontal neighbours, (5,2) vertical ones, the
+// last is tap 8 with a zero weight: its odd half reads tap 5's slot again (inside the 3x3 window, so a finite
+// value) against row 12 of the weight image, which is zero.  A ds_read_b128 is served in groups of 16 lanes that mix the two
 // k-groups g = 0,1 (and 2,3), so those two read the two TAPS of a pair at one 16-byte unit: the slots of a
 // group then differ by 0/1 (stride 1) or an odd number (stride 2) and keep their distinct banks.
 constexpr int dw_tap(int p, int half) {
-    constexpr int t[5][2] = {{0, 1}, {3, 4}, {6, 7}, {2, 5}, {8, 11}};
+    constexpr int t[5][2] = {{0, 1}, {3, 4}, {6, 7}, {5, 2}, {8, 12}};
     return t[p][half];
 }
 #define LDS_READ_U16(dst, addr, off) asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
@@ -170,7 +171,7 @@ template <typename T, int KS1, int CEXP, int PW1> struct ExpStage {
 // bias (the MFMA's C operand), PReLU and rounding IS its half of the project MFMA's B operand for the
 // chunk pair (k = 8 g + j: j < 4 from the even chunk, j >= 4 from the odd one; the project weights are
 // stored in that order when their slice is staged).
-template <typename T, int CEXP, int NT16, int PW3, int ST1> struct DwStage {
+template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB> struct DwStage {
     typedef typename vec8<T>::type V8;
     V8 er[DW_RING][2];             // ring: image unit of a tap pair, per subtile
     V8 a3[4];                      // ring: project fragments
@@ -179,20 +180,24 @@ template <typename T, int CEXP, int NT16, int PW3, int ST1> struct DwStage {
     f32x4 bias, slope;
     f32x4 acc[2];
     V8 bf[2];                      // project B operand of the chunk pair, per subtile
-    int tb[5];                     // LDS address of this lane's unit for tap pair p in subtile 0; + ST1 for subtile 1; + 32 q
-    int w2l[2];                    // this lane's 3x3 weight: [0] tap 0 or 1 (pairs 0..2), [1] tap 2 or 5 (pairs 3, 4); + tap offset + 32 q
+    // LDS address of this lane's unit in subtile 0: [0] tap 0 / 1 (pairs 0, 1, 2 are 0, 1, 2 image rows = ROWB bytes
+    // further), [1] tap 5 / 2 (pair 4 is one row further: tap 8, and for the odd half tap 5's slot with a zero weight);
+    // + ST1 for subtile 1; + 32 q
+    int tb[2];
+    int w2l[2];                    // this lane's 3x3 weight: [0] row 0 or 1 of the weight image (pairs 0..2), [1] row 5 or 9 (pairs 3, 4); + row offset + 32 q
     int pb;                        // depthwise bias quad of channels 4g..; + 64 q; slopes CEXP*4 further
     int w3l;                       // this lane's project weight row 16 (g & 1) + m, unit g >> 1; + 32 n PW3 + 32 pair
 
     template <int ST> __device__ __forceinline__ void issue_taps() {
         constexpr int q = ST / 5, p = ST % 5;
-        LDS_READ16(er[ST % DW_RING][0], tb[p], 32 * q);
-        LDS_READ16(er[ST % DW_RING][1], tb[p], ST1 + 32 * q);
+        constexpr int off = (p < 3 ? p : p - 3) * ROWB + 32 * q;
+        LDS_READ16(er[ST % DW_RING][0], tb[p < 3 ? 0 : 1], off);
+        LDS_READ16(er[ST % DW_RING][1], tb[p < 3 ? 0 : 1], ST1 + off);
     }
     template <int Q, int P> __device__ __forceinline__ void issue_w16() {
-        // pairs 0..2: taps 3 P (+1 for the odd half); pair 3: taps 2 / 5; pair 4: six rows further, tap 8 / the zero row 11
+        // pairs 0..2: rows 3 P (+1 for the odd half); pair 3: rows 5 / 9 (tap 5 / a copy of tap 2); pair 4: three rows further, tap 8 / the zero row 12
         if constexpr (P < 3) LDS_READ_U16(w16[P], w2l[0], 3 * P * (CEXP * 2 + 32) + 32 * Q);
-        else LDS_READ_U16(w16[P], w2l[1], (P - 3) * 6 * (CEXP * 2 + 32) + 32 * Q);
+        else LDS_READ_U16(w16[P], w2l[1], (P - 3) * 3 * (CEXP * 2 + 32) + 32 * Q);
     }
     template <int Q> __device__ __forceinline__ void issue_bias() { LDS_READ16(bias, pb, 64 * Q); }
     template <int Q> __device__ __forceinline__ void issue_slope() { LDS_READ16(slope, pb, CEXP * 4 + 64 * Q); }
@@ -313,7 +318,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     constexpr int OFF_B1 = OFF_PAR, OFF_S1 = OFF_B1 + CEXP * 4, OFF_B2 = OFF_S1 + CEXP * 4, OFF_S2 = OFF_B2 + CEXP * 4,
                   OFF_W2 = OFF_S2 + CEXP * 4;
     constexpr int PW2 = CEXP * 2 + 32;                     // 3x3 weight rows, padded so that the two taps of a pair sit on different banks
-    constexpr int MAIN_BYTES = OFF_W2 + 12 * PW2;     // nine taps, then zeros: "tap 11" is the odd half of the last tap pair
+    constexpr int MAIN_BYTES = OFF_W2 + 13 * PW2;          // rows 0..8 the taps, 9 tap 2 again, 10..12 zero
     constexpr int P32 = COUT * 4 + 16;                     // epilogue staging: f32 pixel rows, padded
     constexpr int EPI_BYTES = POUT * P32;                  // overlays the image and weight buffers
     constexpr int LDS_BYTES = cmax(MAIN_BYTES, EPI_BYTES);
@@ -339,28 +344,33 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 
     // ---- weight-slice staging: global -> registers (issued a slice ahead) -> padded LDS rows ----------
     V8 wreg1[W1_PT], wreg3[W3_PT];
+    const T* W1i = W1;
+    const T* W3i = W3p;
     auto fetch_w = [&](int c) {
+        const int ftid = tid;
 #pragma unroll
         for (int i = 0; i < W1_PT; ++i) {
-            const int v = tid + i * NT;
-            if (v < W1_V) wreg1[i] = *reinterpret_cast<const V8*>(W1 + (size_t)c * 64 * CIN + (size_t)v * 8);
+            const int v = ftid + i * NT;
+            // (wave-uniform base) + (32-bit lane offset): one address register per load instead of a 64-bit pair
+            if (v < W1_V) wreg1[i] = *reinterpret_cast<const V8*>((W1i + c * 64 * CIN) + (unsigned)(v * 8));
         }
 #pragma unroll
         for (int i = 0; i < W3_PT; ++i) {
-            const int v = tid + i * NT;
-            if (v < W3_V) wreg3[i] = *reinterpret_cast<const V8*>(W3p + (size_t)(v >> 3) * CEXP + c * 64 + (v & 7) * 8);
+            const int v = ftid + i * NT;
+            if (v < W3_V) wreg3[i] = *reinterpret_cast<const V8*>((W3i + c * 64) + (unsigned)((v >> 3) * CEXP + (v & 7) * 8));
         }
     };
     auto store_w = [&](int buf) {
+        const int stid = tid;
 #pragma unroll
         for (int i = 0; i < W1_PT; ++i) {
-            const int v = tid + i * NT;
+            const int v = stid + i * NT;
             const int row = v / CH1, ch = v - row * CH1;
             if (v < W1_V) *reinterpret_cast<V8*>(lds + OFF_W1 + buf * W1_BYTES + row * PW1 + ch * 16) = wreg1[i];
         }
 #pragma unroll
         for (int i = 0; i < W3_PT; ++i) {
-            const int v = tid + i * NT;
+            const int v = stid + i * NT;
             // vector u = 4 P + t of row `co` holds positions 32 P + 8 t ..: its low half is the (t >> 1) half of
             // k-group g = 2 (t & 1) of pair P, its high half that of g + 1.  The two k-groups a read group mixes
             // (g even / odd) go to different ROWS at the same unit, which keeps the fragment reads conflict free.
@@ -382,10 +392,11 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         reinterpret_cast<f32x4*>(lds + OFF_B2)[i] = reinterpret_cast<const f32x4*>(b2p)[i];
         reinterpret_cast<f32x4*>(lds + OFF_S2)[i] = reinterpret_cast<const f32x4*>(s2p)[i];
     }
-    for (int i = tid; i < 12 * CEXP / 8; i += NT) {
+    for (int i = tid; i < 13 * CEXP / 8; i += NT) {
         const int row = i / (CEXP / 8), col = i - row * (CEXP / 8);
+        const int src = row == 9 ? 2 : row;
         *reinterpret_cast<u32x4*>(lds + OFF_W2 + row * PW2 + col * 16) =
-            row < 9 ? reinterpret_cast<const u32x4*>(W2p)[i] : u32x4{0u, 0u, 0u, 0u};
+            row < 10 ? reinterpret_cast<const u32x4*>(W2p)[src * (CEXP / 8) + col] : u32x4{0u, 0u, 0u, 0u};
     }
 
     // ---- input fragments (B operand of the expand GEMM), resident while an image's slices are expanded -------
@@ -420,32 +431,20 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     // depthwise and the project product), and that column is never stored.
     constexpr int ST1 = POW == 32 ? 16 * S * SLOT : (16 / POW) * S * PITCH * SLOT;
     static_assert(ST1 + 96 < 65536, "subtile offset must fit the instruction's offset field");
-    int tb[5];            // LDS byte address of unit (g >> 1) of tap dw_tap(p, g & 1) (tap 11 -> tap 7, its weights are zero)
+    static_assert(ST1 + 2 * S * PITCH * SLOT + 96 < 65536, "tap offsets must fit the instruction's offset field");
+    int tb[2];            // LDS byte address of unit (g >> 1) of tap 0 / 1 and of tap 5 / 2 (see DwStage::tb)
     bool out_ok[2];
-    int po[2];
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-        const int rr = 16 * st + m16;
-        const int oy = wave * RPT + rr / POW, ox = rr % POW;
-        out_ok[st] = (ox < Wo) && (oy < TR);
-        po[st] = oy * Wo + ox;
-    }
+    int po0;              // this lane's pixel of subtile 0 inside the band; subtile 1 is PO1 further
+    constexpr int PO1 = POW == 32 ? 16 : (16 / POW) * Wo;
     {
         const int oy = wave * RPT + m16 / POW, ox = m16 % POW;
-#pragma unroll
-        for (int p = 0; p < 5; ++p) {
-            const int t9 = (g4 & 1) ? dw_tap(p, 1) : dw_tap(p, 0);
-            const int tap = t9 > 8 ? 7 : t9;
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            tb[p] = ((oy * S + ky) * PITCH + ox * S + kx) * SLOT + 16 * (g4 >> 1);
-        }
+        po0 = oy * Wo + ox;
+        out_ok[0] = (ox < Wo) && (oy < TR);
+        out_ok[1] = POW == 32 ? (ox + 16 < Wo) && (oy < TR) : (ox < Wo) && (oy + 16 / POW < TR);
+        const int h1 = g4 & 1;
+        tb[0] = ((oy * S) * PITCH + ox * S + h1) * SLOT + 16 * (g4 >> 1);              // tap 0 = (0,0) / tap 1 = (0,1)
+        tb[1] = ((oy * S + 1 - h1) * PITCH + ox * S + 2) * SLOT + 16 * (g4 >> 1);      // tap 5 = (1,2) / tap 2 = (0,2)
     }
-    // diagonal fragment: element j of register pair j >> 1 is non-zero where channel 8 (g >> 1) + j is this lane's row
-    uint32_t dmask[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        dmask[i] = ((m16 >> 3) == (g4 >> 1) && ((m16 & 7) >> 1) == i) ? ((m16 & 1) ? 0xFFFF0000u : 0x0000FFFFu) : 0u;
-
     // project accumulators: tile n of subtile st, register i <-> output channel 16 n + 4 g + i; the bias joins in the epilogue
     f32x4 pacc[2][NT16];
 
@@ -494,13 +493,16 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     // ================= depthwise 3x3 of slice c from the LDS image -> project MFMA =================================
     auto dwproject = [&](int c, int wb, int eb) {
         if (wave >= MTO) return;                           // wave-uniform
-        DwStage<T, CEXP, NT16, PW3, ST1> dw;
+        DwStage<T, CEXP, NT16, PW3, ST1, PITCH * SLOT> dw;
+        dw.tb[0] = tb[0] + eb * ES_BYTES;
+        dw.tb[1] = tb[1] + eb * ES_BYTES;
+        // diagonal fragment: element j of register pair j >> 1 is non-zero where channel 8 (g >> 1) + j is this lane's row
+        // (rebuilt per slice from the lane index: four registers that need not live through the expand stage)
 #pragma unroll
-        for (int p = 0; p < 5; ++p) dw.tb[p] = tb[p] + eb * ES_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dw.msk[i] = dmask[i];
+        for (int i = 0; i < 4; ++i)
+            dw.msk[i] = ((m16 >> 3) == (g4 >> 1) && ((m16 & 7) >> 1) == i) ? ((m16 & 1) ? 0xFFFF0000u : 0x0000FFFFu) : 0u;
         dw.w2l[0] = OFF_W2 + (g4 & 1) * PW2 + (64 * c + m16) * 2;
-        dw.w2l[1] = OFF_W2 + (2 + 3 * (g4 & 1)) * PW2 + (64 * c + m16) * 2;
+        dw.w2l[1] = OFF_W2 + (5 + 4 * (g4 & 1)) * PW2 + (64 * c + m16) * 2;
         dw.pb = OFF_B2 + 256 * c + 16 * g4;
         dw.w3l = OFF_W3 + wb * W3_BYTES + (16 * (g4 & 1) + m16) * PW3 + 16 * (g4 >> 1);
 #ifdef DW_YOUNG_PRIO
@@ -571,9 +573,11 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         constexpr int G = COUT / 4, UNITS = POUT * G;
         constexpr int EPI_IT = (UNITS + NT - 1) / NT, EPI_CH = 4, EPI_NCH = (EPI_IT + EPI_CH - 1) / EPI_CH;
         constexpr int PSTEP = NT / G;                          // pixels between two units of a thread
-        const int g = tid % G, p0 = tid / G;
+        const int etid = tid;
+        const int g = etid % G, p0 = etid / G;
         const size_t pix0 = (size_t)img * Ho * Wo + (size_t)y0 * Wo;
-        const T* xs = X + (pix0 + p0) * CIN + 4 * g;          // only dereferenced when RESID
+        const T* xs = X + pix0 * CIN;                          // wave-uniform; only dereferenced when RESID
+        const unsigned xo = p0 * CIN + 4 * g, oo = p0 * COUT + 4 * g;
         V4 rr[2][EPI_CH];
         auto fetch_shortcut = [&](auto chunk) {
             constexpr int k = decltype(chunk)::value;
@@ -581,7 +585,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     #pragma unroll
                 for (int j = 0; j < EPI_CH; ++j) {
                     const int it = k * EPI_CH + j;
-                    if (it < EPI_IT && p0 + it * PSTEP < POUT) rr[k & 1][j] = *reinterpret_cast<const V4*>(xs + (size_t)it * PSTEP * CIN);
+                    if (it < EPI_IT && p0 + it * PSTEP < POUT) rr[k & 1][j] = *reinterpret_cast<const V4*>(xs + (xo + it * PSTEP * CIN));
                 }
             }
         };
@@ -590,7 +594,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     #pragma unroll
             for (int st = 0; st < 2; ++st)
                 if (out_ok[st]) {
-                    char* dst = lds + po[st] * P32 + 16 * g4;
+                    char* dst = lds + (po0 + st * PO1) * P32 + 16 * g4;
     #pragma unroll
                     for (int n = 0; n < NT16; ++n) *reinterpret_cast<f32x4*>(dst + 64 * n) = pacc[st][n];
                 }
@@ -598,7 +602,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         __syncthreads();
         {
             const f32x4 bias = *reinterpret_cast<const f32x4*>(b3 + 4 * g);
-            T* os = O + (pix0 + p0) * COUT + 4 * g;
+            T* os = O + pix0 * COUT;
             const char* ls = lds + p0 * P32 + g * 16;
             static_for<EPI_NCH>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
@@ -615,7 +619,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
                         V4 o;
     #pragma unroll
                         for (int i = 0; i < 4; ++i) o[i] = (T)(v[i] + bias[i]);
-                        *reinterpret_cast<V4*>(os + (size_t)it * PSTEP * COUT) = o;
+                        *reinterpret_cast<V4*>(os + (oo + it * PSTEP * COUT)) = o;
                     }
                 }
             });
@@ -629,7 +633,7 @@ template <int CIN, int CEXP, int COUT, int H, int S, int TR, int MODE>
 constexpr int block_lds_bytes() {
     constexpr int RIN = (S == 1) ? TR + 2 : 2 * TR + 1;
     constexpr int main_bytes = RIN * block_pitch<H, S>() * 144 +
-                               (MODE >= 1 ? 2 : 1) * (64 * (CIN * 2 + 16) + COUT * 160) + 4 * CEXP * 4 + 12 * (CEXP * 2 + 32);
+                               (MODE >= 1 ? 2 : 1) * (64 * (CIN * 2 + 16) + COUT * 160) + 4 * CEXP * 4 + 13 * (CEXP * 2 + 32);
     constexpr int epi_bytes = TR * (H / S) * (COUT * 4 + 16);
     return cmax(main_bytes, epi_bytes);
 }
