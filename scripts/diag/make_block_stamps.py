@@ -37,7 +37,7 @@ rep("                expand(c, c & 1, 0);\n                if (c == NCH - 1 && h
     "                expand(c, c & 1, 0);\n                if (c == NCH - 1 && has_next) load_x(img + gridDim.y);\n                ISTAMP(3 + 5 * c);\n                __syncthreads();\n                ISTAMP(4 + 5 * c);\n                dwproject(c, c & 1, 0);\n                ISTAMP(5 + 5 * c);\n")
 rep("                __syncthreads();                       // image and old weights free, new weights visible\n            }\n",
     "                ISTAMP(6 + 5 * c);\n                __syncthreads();\n                ISTAMP(7 + 5 * c);\n            }\n")
-rep("        __syncthreads();\n        {\n            constexpr int G = COUT / 4", "        ISTAMP(24);\n        __syncthreads();\n        ISTAMP(25);\n        {\n            constexpr int G = COUT / 4")
+rep("        __syncthreads();\n        {\n            const f32x4 bias =", "        ISTAMP(24);\n        __syncthreads();\n        ISTAMP(25);\n        {\n            const f32x4 bias =")
 rep("        if (has_next) __syncthreads();   // staging reads are done before the region is zeroed and restaged\n",
     "        ISTAMP(26);\n        if (has_next) __syncthreads();\n        ISTAMP(27);\n        ++dbg_it;\n")
 rep("        if (has_next) __syncthreads();\n        ISTAMP(27);\n        ++dbg_it;\n    }\n}",
