@@ -97,11 +97,21 @@ struct BlockParams {
     const void* w2p;    // T [9][cexp] permuted, tap-major
     const float* b2p;
     const float* s2p;   // [cexp] permuted, PReLU slope MINUS ONE
-    const void* w3p;    // T [cout][cexp], columns permuted
+    const void* w3p;    // T, cout * cexp elements in the order w3_image_index() defines (the project stage's LDS image)
     const float* b3;    // [cout]
 };
 // position of natural expanded channel c = 16g + 8a + 4h + i in the permuted order: 16g + 8h + 4a + i
 inline int perm_pos(int c) { return (c & ~15) | ((c & 4) << 1) | ((c & 8) >> 1) | (c & 3); }
+// Where element (output channel co, expanded-channel POSITION pos = perm_pos(channel)) of the project weights is
+// stored: slice-major (64 positions per slice), inside a slice exactly the order the kernel keeps in LDS, so that
+// a slice is copied with 16-byte LDS-DMA pieces.  Row 32 n + 16 (g & 1) + m of a slice holds, for output channel
+// 16 n + m, four 16-byte units [pair P][g >> 1]; unit element j is position 32 P + 4 g + j (j < 4) or
+// 32 P + 16 + 4 g + (j - 4): k-group g of the project MFMA whose B operand a lane builds from two 16-channel chunks.
+inline size_t w3_image_index(int co, int pos, int cout) {
+    const int c = pos >> 6, P = (pos >> 5) & 1, hi = (pos >> 4) & 1, g = (pos >> 2) & 3, i = pos & 3;
+    const int row = 32 * (co >> 4) + 16 * (g & 1) + (co & 15), unit = 2 * P + (g >> 1), j = 4 * hi + i;
+    return (((size_t)c * 2 * cout + row) * 4 + unit) * 8 + j;
+}
 int launch_block(int dt, const BlockParams& p, const void* x, void* out, int B, hipStream_t s);
 // fused head: stem conv (3->64, 3x3 s2, PReLU) + depthwise 3x3 (64 ch, PReLU) -> out T NHWC [B,56,56,64].
 // x: n_src crops, f32 NCHW in [-1,1] or (x_is_u8) uint8 HWC; images n_src..B-1 are mirrored copies of images 0..B-n_src-1

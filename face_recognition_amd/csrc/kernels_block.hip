@@ -109,6 +109,9 @@ constexpr int dw_tap(int p, int half) {
 }
 #define LDS_READ_U16(dst, addr, off) asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) void* GPTR;  // global source of an LDS-DMA load
+typedef __attribute__((address_space(3))) void* LPTR;        // its (wave-uniform) LDS destination
+__device__ __forceinline__ int cmin_rt(int a, int b) { return a < b ? a : b; }
 
 
 template <int H, int S> constexpr int block_pitch() {
@@ -309,22 +312,27 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     constexpr int PITCH = block_pitch<H, S>();
     constexpr int SLOT = 144;                              // bytes per pixel slot: 64 channels + one unit of padding
     // padded row pitch of the W1 slice; the W3 slice is stored as rows of 64 + 16 bytes: row 32 n + 16 (g & 1) + m
-    // holds, for output channel 16 n + m, the units [pair][g >> 1] of k-group g (see store_w)
+    // holds, for output channel 16 n + m, the units [pair][g >> 1] of k-group g (w3_image_index() in common.h)
     constexpr int PW1 = CIN * 2 + 16, PW3 = 80;
     constexpr int ES_BYTES = RIN * PITCH * SLOT;
-    constexpr int W1_BYTES = 64 * PW1, W3_BYTES = 2 * COUT * PW3;
-    constexpr int NWB = MODE >= 1 ? 2 : 1;                 // LDS copies of each weight slice
-    constexpr int OFF_W1 = ES_BYTES, OFF_W3 = OFF_W1 + NWB * W1_BYTES, OFF_PAR = OFF_W3 + NWB * W3_BYTES;
+    constexpr int W1_BYTES = 64 * PW1, W3_BYTES = 2 * COUT * PW3, WB_BYTES = W1_BYTES + W3_BYTES;
+    constexpr int P32 = COUT * 4 + 16;                     // epilogue staging: f32 pixel rows, padded
+    constexpr int EPI_BYTES = POUT * P32;                  // overlays the image and weight buffer 1
+    constexpr int PW2 = CEXP * 2 + 32;                     // 3x3 weight rows, padded so that the two taps of a pair sit on different banks
+    // LDS map: image | weight buffer 1 (odd slices) | per-channel parameters | 3x3 weights | weight buffer 0 (even
+    // slices).  The epilogue's staging rows overlay the image and buffer 1 only: buffer 0 can receive the next
+    // image's first slice while this image's last slice and epilogue still run.
+    constexpr int OFF_WB1 = ES_BYTES;
+    constexpr int OFF_PAR = (cmax(OFF_WB1 + WB_BYTES, EPI_BYTES) + 15) / 16 * 16;
     constexpr int OFF_B1 = OFF_PAR, OFF_S1 = OFF_B1 + CEXP * 4, OFF_B2 = OFF_S1 + CEXP * 4, OFF_S2 = OFF_B2 + CEXP * 4,
                   OFF_W2 = OFF_S2 + CEXP * 4;
-    constexpr int PW2 = CEXP * 2 + 32;                     // 3x3 weight rows, padded so that the two taps of a pair sit on different banks
-    constexpr int MAIN_BYTES = OFF_W2 + 13 * PW2;          // rows 0..8 the taps, 9 tap 2 again, 10..12 zero
-    constexpr int P32 = COUT * 4 + 16;                     // epilogue staging: f32 pixel rows, padded
-    constexpr int EPI_BYTES = POUT * P32;                  // overlays the image and weight buffers
-    constexpr int LDS_BYTES = cmax(MAIN_BYTES, EPI_BYTES);
+    constexpr int OFF_WB0 = OFF_W2 + 13 * PW2;             // 3x3 weights: rows 0..8 the taps, 9 tap 2 again, 10..12 zero
+    constexpr int LDS_BYTES = OFF_WB0 + WB_BYTES;
     constexpr int CH1 = CIN / 8;
-    constexpr int W1_V = 64 * CH1, W3_V = COUT * 8;        // 16-byte vectors per slice
-    constexpr int W1_PT = (W1_V + NT - 1) / NT, W3_PT = (W3_V + NT - 1) / NT;
+    // a weight slice arrives by LDS-DMA in pieces of 64 lanes x 16 bytes = 1 KB of the padded LDS image
+    constexpr int NI1 = W1_BYTES / 1024, NI3 = W3_BYTES / 1024;
+    static_assert(W1_BYTES % 1024 == 0 && W3_BYTES % 1024 == 0, "weight images are whole DMA pieces");
+    static_assert(MODE == 1, "two copies of the weight slices");
     static_assert(CEXP % 64 == 0 && CIN % 16 == 0 && COUT % 32 == 0 && Ho % TR == 0, "shape");
     constexpr int MTIW = (MTI + NW - 1) / NW;              // input tiles per wave (stride-2 bands have more input than output)
     static_assert(MTO <= NW, "one output tile per wave");
@@ -332,6 +340,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(NT % (COUT / 4) == 0, "epilogue: a thread keeps one channel group");
     static_assert(EPI_BYTES <= OFF_PAR, "the epilogue staging must not reach the per-channel parameters");
+    static_assert(NCH % 2 == 0, "slice 0 of the next image goes to the buffer the last slice does not use");
     static_assert(NCH >= 2, "the weight pipeline below assumes at least two slices");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
@@ -342,48 +351,32 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     const int y0 = band * TR;                              // first output row of the band
     const int row0 = WHOLE ? 0 : ((S == 1) ? y0 - 1 : 2 * y0 - 1);   // image row of the first computed input row
 
-    // ---- weight-slice staging: global -> registers (issued a slice ahead) -> padded LDS rows ----------
-    V8 wreg1[W1_PT], wreg3[W3_PT];
-    const T* W1i = W1;
-    const T* W3i = W3p;
-    auto fetch_w = [&](int c) {
-        const int ftid = tid;
+    // ---- weight-slice staging by LDS-DMA: piece k of an image is written by wave k % NW; lane l supplies the
+    // 16-byte granule 64 k + l of the padded image from wherever it lives in global memory (a padding granule
+    // re-reads its row's last unit).  No registers, no store pass; the wave that issued a piece waits for it
+    // (vmcnt) before the barrier that publishes the buffer.
+    auto stage_w = [&](int c, int buf) {
+        char* l1 = lds + (buf ? OFF_WB1 : OFF_WB0);
+        const T* g1 = W1 + c * 64 * CIN;
+        const T* g3 = W3p + c * (2 * COUT * 32);
 #pragma unroll
-        for (int i = 0; i < W1_PT; ++i) {
-            const int v = ftid + i * NT;
-            // (wave-uniform base) + (32-bit lane offset): one address register per load instead of a 64-bit pair
-            if (v < W1_V) wreg1[i] = *reinterpret_cast<const V8*>((W1i + c * 64 * CIN) + (unsigned)(v * 8));
+        for (int j = 0; j < (NI1 + NW - 1) / NW; ++j) {
+            const int k = wave + NW * j;
+            if (k < NI1) {                                 // wave-uniform
+                const int G = 64 * k + lane, row = G / (CH1 + 1), col = cmin_rt(G - row * (CH1 + 1), CH1 - 1);
+                __builtin_amdgcn_global_load_lds((GPTR)(g1 + (unsigned)(row * CIN + col * 8)), (LPTR)(l1 + k * 1024), 16, 0, 0);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < W3_PT; ++i) {
-            const int v = ftid + i * NT;
-            if (v < W3_V) wreg3[i] = *reinterpret_cast<const V8*>((W3i + c * 64) + (unsigned)((v >> 3) * CEXP + (v & 7) * 8));
-        }
-    };
-    auto store_w = [&](int buf) {
-        const int stid = tid;
-#pragma unroll
-        for (int i = 0; i < W1_PT; ++i) {
-            const int v = stid + i * NT;
-            const int row = v / CH1, ch = v - row * CH1;
-            if (v < W1_V) *reinterpret_cast<V8*>(lds + OFF_W1 + buf * W1_BYTES + row * PW1 + ch * 16) = wreg1[i];
-        }
-#pragma unroll
-        for (int i = 0; i < W3_PT; ++i) {
-            const int v = stid + i * NT;
-            // vector u = 4 P + t of row `co` holds positions 32 P + 8 t ..: its low half is the (t >> 1) half of
-            // k-group g = 2 (t & 1) of pair P, its high half that of g + 1.  The two k-groups a read group mixes
-            // (g even / odd) go to different ROWS at the same unit, which keeps the fragment reads conflict free.
-            if (v < W3_V) {
-                const int co = v >> 3, u = v & 7, t = u & 3;
-                char* dst = lds + OFF_W3 + buf * W3_BYTES + (32 * (co >> 4) + (co & 15)) * PW3 + (2 * (u >> 2) + (t & 1)) * 16 + (t >> 1) * 8;
-                const u32x4 w = __builtin_bit_cast(u32x4, wreg3[i]);
-                *reinterpret_cast<uint2*>(dst) = uint2{w[0], w[1]};
-                *reinterpret_cast<uint2*>(dst + 16 * PW3) = uint2{w[2], w[3]};
+        for (int j = 0; j < (NI3 + NW - 1) / NW; ++j) {
+            const int k = wave + NW * j;
+            if (k < NI3) {
+                const int G = 64 * k + lane, row = G / 5, u = cmin_rt(G - row * 5, 3);
+                __builtin_amdgcn_global_load_lds((GPTR)(g3 + (unsigned)(row * 32 + u * 8)), (LPTR)(l1 + W1_BYTES + k * 1024), 16, 0, 0);
             }
         }
     };
-    fetch_w(0);
+    stage_w(0, 0);
 
     // per-channel parameters of all slices
     for (int i = tid; i < CEXP / 4; i += NT) {
@@ -476,7 +469,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         if (wave >= MTI) return;                           // wave-uniform; such a wave has no later tile either
         const int eoff = eb * ES_BYTES;
         Ex ex;   // lives only inside this call, so its registers are free for the other stage
-        ex.w1l = OFF_W1 + wb * W1_BYTES + r * PW1 + 16 * h;
+        ex.w1l = (wb ? OFF_WB1 : OFF_WB0) + r * PW1 + 16 * h;
         ex.pl = OFF_B1 + 256 * c + 32 * h;
         ex.template issue<0>();
         expand_tile(ex, 0, std::true_type{}, 0, eoff);
@@ -504,7 +497,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         dw.w2l[0] = OFF_W2 + (g4 & 1) * PW2 + (64 * c + m16) * 2;
         dw.w2l[1] = OFF_W2 + (5 + 4 * (g4 & 1)) * PW2 + (64 * c + m16) * 2;
         dw.pb = OFF_B2 + 256 * c + 16 * g4;
-        dw.w3l = OFF_W3 + wb * W3_BYTES + (16 * (g4 & 1) + m16) * PW3 + 16 * (g4 >> 1);
+        dw.w3l = (wb ? OFF_WB1 : OFF_WB0) + W1_BYTES + (16 * (g4 & 1) + m16) * PW3 + 16 * (g4 >> 1);
 #ifdef DW_YOUNG_PRIO
         if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);   // the later-dispatched wave of a SIMD otherwise loses every arbitration
 #endif
@@ -518,51 +511,34 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     // A workgroup keeps its band and walks over images blockIdx.y, blockIdx.y + gridDim.y, ...: the per-channel
     // parameters are staged once, and the next image's input fragments and first weight slice are
     // requested while the current image's last slice and epilogue still run.
-    static_assert(MODE == 0 || MODE == 1, "modes: 0 = one copy of the weight slices, 1 = two");
     for (int img = blockIdx.y; img < B; img += gridDim.y) {
         const bool has_next = img + (int)gridDim.y < B;
         // zero the activation image: borders and out-of-image rows are never written by the expand stage
         // (the previous image's epilogue used this memory as staging)
         for (int i = tid; i < ES_BYTES / 16; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        store_w(0);
-        fetch_w(1);
+        // first image: this wave's pieces of slice 0, requested above.  Later images: they were waited for at the end of
+        // the previous image's last slice, and waiting here would only drain that image's output stores.
+        if (img == (int)blockIdx.y) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
             for (int n = 0; n < NT16; ++n) pacc[st][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (MODE == 1) {
-            // expand | barrier | depthwise+project, next slice's weights into the other buffer | barrier
+        // per slice: request the next slice's weights (or the next image's first slice) into the other buffer |
+        // expand | barrier | depthwise + project | wait for the requested pieces | barrier
 #pragma unroll 1
-            for (int c = 0; c < NCH; ++c) {
-                expand(c, c & 1, 0);
-                if (c == NCH - 1 && has_next) load_x(img + gridDim.y);   // the fragments are dead after the last expand
-                __syncthreads();                       // the image of slice c is complete
-                dwproject(c, c & 1, 0);
-                if (c + 1 < NCH) {
-                    store_w((c + 1) & 1);              // that buffer was last read before the previous barrier
-                    // one load site for both cases (the next slice, or the next image's first slice, which is
-                    // stored after the epilogue), so the loads stay here, a whole slice ahead of their use
-                    if (c + 2 < NCH || has_next) fetch_w(c + 2 < NCH ? c + 2 : 0);
-                }
-                __syncthreads();                       // image and old weights free, new weights visible
-            }
-        } else {
-            // one copy of the weight slices (less LDS, so that two workgroups share a CU and fill each
-            // other's barrier waits): expand | barrier | depthwise+project | barrier | restage | barrier
-#pragma unroll 1
-            for (int c = 0; c < NCH; ++c) {
-                expand(c, 0, 0);
-                if (c == NCH - 1 && has_next) load_x(img + gridDim.y);
-                __syncthreads();
-                dwproject(c, 0, 0);
-                __syncthreads();
-                if (c + 1 < NCH) {
-                    store_w(0);
-                    if (c + 2 < NCH || has_next) fetch_w(c + 2 < NCH ? c + 2 : 0);
-                    __syncthreads();
-                }
-            }
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH) stage_w(c + 1, (c + 1) & 1);  // that buffer was last read before the previous barrier
+            else if (has_next) stage_w(0, 0);
+            expand(c, c & 1, 0);
+            if (c == NCH - 1 && has_next) load_x(img + gridDim.y);   // the fragments are dead after the last expand
+            // the image of slice c is complete.  Not __syncthreads(): its fence would also wait for the LDS-DMA in flight
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            dwproject(c, c & 1, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                           // image and old weights free, new weights visible
         }
 
         // ---- epilogue: accumulators -> f32 pixel rows in LDS -> (+ bias, + shortcut) -> NHWC, 8 bytes per lane -------
@@ -631,11 +607,13 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 // ---------------------------------------------------------------------------------------------
 template <int CIN, int CEXP, int COUT, int H, int S, int TR, int MODE>
 constexpr int block_lds_bytes() {
+    // mirrors the LDS map of block_kernel
     constexpr int RIN = (S == 1) ? TR + 2 : 2 * TR + 1;
-    constexpr int main_bytes = RIN * block_pitch<H, S>() * 144 +
-                               (MODE >= 1 ? 2 : 1) * (64 * (CIN * 2 + 16) + COUT * 160) + 4 * CEXP * 4 + 13 * (CEXP * 2 + 32);
-    constexpr int epi_bytes = TR * (H / S) * (COUT * 4 + 16);
-    return cmax(main_bytes, epi_bytes);
+    constexpr int es = RIN * block_pitch<H, S>() * 144;
+    constexpr int wb = 64 * (CIN * 2 + 16) + COUT * 160;
+    constexpr int epi = TR * (H / S) * (COUT * 4 + 16);
+    constexpr int off_par = (cmax(es + wb, epi) + 15) / 16 * 16;
+    return off_par + 4 * CEXP * 4 + 13 * (CEXP * 2 + 32) + wb;
 }
 
 // workgroups of `kernel` that fit on the current device at once (occupancy x compute units)

@@ -317,7 +317,7 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
             if ((rc = fetch(m, o.name + ".project.conv.weight", (int64_t)C * CE, &w))) return rc;
             if ((rc = bn_fold(m, o.name + ".project.bn", C, scale, shift))) return rc;
             for (int n = 0; n < C; ++n) {
-                for (int e = 0; e < CE; ++e) w3p[(size_t)n * CE + perm_pos(e)] = to16(dt, (float)(w[(size_t)n * CE + e] * scale[n]));
+                for (int e = 0; e < CE; ++e) w3p[w3_image_index(n, perm_pos(e), C)] = to16(dt, (float)(w[(size_t)n * CE + e] * scale[n]));
                 b3[n] = (float)shift[n];
             }
             continue;

@@ -116,8 +116,11 @@ int mfn_op_dw3x3(int dtype, const void* in, const void* w9xC, const float* bias,
 int mfn_op_pw(int dtype, const void* in, const void* wNxK, const float* bias, const float* slope_or_null,
               const void* resid_or_null, void* out, int64_t M, int K, int N, fra_stream stream);
 /* Fused inverted-residual block (face_model.py:55-65).  Arrays indexed by expanded channel on the
- * depthwise / project side (b1p, s1p, w2p [9][cexp], b2p, s2p, columns of w3p [cout][cexp]) are in
- * the kernel's permuted channel order: natural channel 16g+8a+4h+i is stored at 16g+8h+4a+i.
+ * depthwise / project side (b1p, s1p, w2p [9][cexp], b2p, s2p) are in the kernel's permuted channel
+ * order: natural channel 16g+8a+4h+i is stored at POSITION 16g+8h+4a+i.  w3p holds the cout x cexp
+ * project weights slice-major in the order the project stage reads them: with pos the position of the
+ * expanded channel, c = pos/64, P = (pos/32)%2, hi = (pos/16)%2, g = (pos/4)%4, i = pos%4, element
+ * (co, pos) sits at ((c*2*cout + 32*(co/16) + 16*(g%2) + co%16)*4 + 2*P + g/2)*8 + 4*hi + i.
  * s1p / s2p hold (PReLU slope - 1): the kernel evaluates v + (slope-1)*min(v,0). */
 int mfn_op_block(int dtype, int cin, int cexp, int cout, int h, int stride, int residual, const void* x,
                  const void* w1, const float* b1p, const float* s1p, const void* w2p, const float* b2p,

@@ -32,11 +32,12 @@ rep("    const int band = blockIdx.x;\n",
 s = s.replace("#define STAMP(i) ", "#define STAMP_RAW(i) ")
 s = s.replace("extern \"C\" int fra_dbg_read", "#define STAMP(i) STAMP_RAW(i)\n#define ISTAMP(i) do { if (dbg_it < 2) STAMP_RAW(30 * dbg_it + (i)); } while (0)\nextern \"C\" int fra_dbg_read")
 rep("        const bool has_next = img + (int)gridDim.y < B;\n", "        const bool has_next = img + (int)gridDim.y < B;\n        ISTAMP(0);\n")
-rep("        store_w(0);\n        fetch_w(1);\n        __syncthreads();\n", "        store_w(0);\n        fetch_w(1);\n        ISTAMP(1);\n        __syncthreads();\n        ISTAMP(2);\n")
-rep("                expand(c, c & 1, 0);\n                if (c == NCH - 1 && has_next) load_x(img + gridDim.y);   // the fragments are dead after the last expand\n                __syncthreads();                       // the image of slice c is complete\n                dwproject(c, c & 1, 0);\n",
-    "                expand(c, c & 1, 0);\n                if (c == NCH - 1 && has_next) load_x(img + gridDim.y);\n                ISTAMP(3 + 5 * c);\n                __syncthreads();\n                ISTAMP(4 + 5 * c);\n                dwproject(c, c & 1, 0);\n                ISTAMP(5 + 5 * c);\n")
-rep("                __syncthreads();                       // image and old weights free, new weights visible\n            }\n",
-    "                ISTAMP(6 + 5 * c);\n                __syncthreads();\n                ISTAMP(7 + 5 * c);\n            }\n")
+rep('        if (img == (int)blockIdx.y) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        __syncthreads();\n',
+    '        if (img == (int)blockIdx.y) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n        ISTAMP(1);\n        __syncthreads();\n        ISTAMP(2);\n')
+rep("            if (c == NCH - 1 && has_next) load_x(img + gridDim.y);   // the fragments are dead after the last expand\n",
+    "            if (c == NCH - 1 && has_next) load_x(img + gridDim.y);\n            ISTAMP(3 + 5 * c);\n")
+rep('            asm volatile("" ::: "memory");\n            dwproject(c, c & 1, 0);\n            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n            __syncthreads();                           // image and old weights free, new weights visible\n',
+    '            asm volatile("" ::: "memory");\n            ISTAMP(4 + 5 * c);\n            dwproject(c, c & 1, 0);\n            ISTAMP(5 + 5 * c);\n            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n            ISTAMP(6 + 5 * c);\n            __syncthreads();\n            ISTAMP(7 + 5 * c);\n')
 rep("        __syncthreads();\n        {\n            const f32x4 bias =", "        ISTAMP(24);\n        __syncthreads();\n        ISTAMP(25);\n        {\n            const f32x4 bias =")
 rep("        if (has_next) __syncthreads();   // staging reads are done before the region is zeroed and restaged\n",
     "        ISTAMP(26);\n        if (has_next) __syncthreads();\n        ISTAMP(27);\n        ++dbg_it;\n")

@@ -107,6 +107,20 @@ def _perm(c):
     return (c & ~15) | ((c & 4) << 1) | ((c & 8) >> 1) | (c & 3)
 
 
+def _w3_image(w3pos, cout):
+    """Project weights [cout, cexp] (columns in position order) -> the slice-major order mfn_op_block reads
+    (include/face_recognition_amd.h)."""
+    cexp = w3pos.shape[1]
+    co = torch.arange(cout).view(-1, 1).expand(cout, cexp)
+    pos = torch.arange(cexp).view(1, -1).expand(cout, cexp)
+    c, P, hi, g, i = pos // 64, (pos // 32) % 2, (pos // 16) % 2, (pos // 4) % 4, pos % 4
+    idx = ((c * 2 * cout + 32 * (co // 16) + 16 * (g % 2) + co % 16) * 4 + 2 * P + g // 2) * 8 + 4 * hi + i
+    out = torch.empty(cout * cexp, dtype=w3pos.dtype)
+    out[idx.reshape(-1)] = w3pos.reshape(-1)
+    assert idx.unique().numel() == cout * cexp
+    return out
+
+
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("cin,cexp,cout,H,stride,res,B", [(64, 128, 64, 56, 2, False, 2), (64, 128, 64, 28, 1, True, 3),
                                                          (64, 256, 128, 28, 2, False, 2), (128, 256, 128, 14, 1, True, 3),
@@ -138,7 +152,7 @@ def test_fused_block(device, dt, cin, cexp, cout, H, stride, res, B):
     w1d, b1d, s1d = dev(w1.to(tdt)), dev(b1[inv]), dev(s1[inv] - 1.0)      # slopes travel as slope - 1
     w2d = dev(w2.reshape(cexp, 9).t()[:, inv].to(tdt))
     b2d, s2d = dev(b2[inv]), dev(s2[inv] - 1.0)
-    w3d, b3d = dev(w3[:, inv].to(tdt)), dev(b3)
+    w3d, b3d = dev(_w3_image(w3[:, inv], cout).to(tdt)), dev(b3)
     Ho = H // stride
     out = torch.full((B, Ho, Ho, cout), float("nan"), dtype=tdt, device=device)
     _lib.check(lib.mfn_op_block(code, cin, cexp, cout, H, stride, int(res), xd.data_ptr(), w1d.data_ptr(),
