@@ -16,14 +16,15 @@
 //      B operand -- the depthwise output never exists in memory at all.
 // Project accumulators live in registers across slices.  The epilogue turns them into rows of
 // pixels through LDS so that the shortcut is read and the result written with contiguous 8-byte
-// pieces per lane.  The weight-matrix slices of the next 64 channels are fetched into registers
-// while the current slice computes and stored into the other of two LDS buffers.
+// pieces per lane.  The weight-matrix slices of the next 64 channels arrive by LDS-DMA in the other of
+// two LDS buffers while the current slice computes (no staging registers, no store pass).
 //
 // LDS layout.  Every tile that is read as MFMA fragments or by the depthwise stage has rows of
-// 16-byte units with one unit of padding (a pixel slot of the image is 128 + 16 bytes, a weight row
-// CIN*2 + 16 or 128 + 16 bytes): 16 lanes that read the same unit of 16 consecutive rows then hit
-// 16 different 16-byte columns of the 256-byte bank window, and every unit / k-step / tap offset
-// is a compile-time constant that goes into the instruction's offset field.
+// 16-byte units with one unit of padding (a pixel slot of the image is 128 + 16 bytes, an expand
+// weight row CIN*2 + 16, a project weight row 64 + 16 bytes): 16 lanes that read the same unit of 16
+// consecutive rows then hit 16 different 16-byte columns of the 256-byte bank window, and every
+// unit / k-step / tap offset is a compile-time constant that goes into the instruction's offset
+// field.
 //
 // The LDS reads of both stages are issued by hand ahead of their use, with counted waits: LDS
 // returns data in order, so "at most n reads outstanding" (s_waitcnt lgkmcnt(n)) says exactly
@@ -34,8 +35,8 @@
 // Channel order inside the expanded tensor: a lane of half h of the expand MFMA ends up with
 // channels 8q+4h+i (q<4, i<4) of each 32-channel tile; storing natural channel 16g + 8a + 4h + i at
 // position 16g + 8h + 4a + i lets it write them as 16-byte units.  Everything indexed by expanded
-// channel on the depthwise/project side (bias, slope, 3x3 weights, project weight columns) is
-// stored in that position order on the host.  The two slope arrays hold (PReLU slope - 1):
+// channel on the depthwise/project side (bias, slope, 3x3 weights) is stored in that position order
+// on the host; the project weights are stored as the LDS image of each slice (w3_image_index()).  The two slope arrays hold (PReLU slope - 1):
 // prelu(v) = v + (slope-1) min(v,0).
 #include <utility>
 
@@ -69,10 +70,7 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 //              at p == 4 after the PReLU: slope(q+1), then for q odd the project loop
 //              { WAIT fragment n; two MFMAs; issue fragment n + 4 }.
 // dw_outstanding() replays that order and returns the number of reads issued after the awaited one.
-#ifndef DW_PD_VALUE
-#define DW_PD_VALUE 2
-#endif
-constexpr int DW_STEPS = 20, DW_PD = DW_PD_VALUE, DW_RING = DW_PD + 1;
+constexpr int DW_STEPS = 20, DW_PD = 2, DW_RING = DW_PD + 1;   // reads run DW_PD steps ahead (3 measured no faster)
 constexpr int dw_outstanding(int nt16, int kind, int st, int n) {   // kind 0: taps(st); kind 1: fragment n in step st
     int issued = 7;
     int taps_idx[DW_STEPS] = {};
@@ -498,14 +496,8 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         dw.w2l[1] = OFF_W2 + (5 + 4 * (g4 & 1)) * PW2 + (64 * c + m16) * 2;
         dw.pb = OFF_B2 + 256 * c + 16 * g4;
         dw.w3l = (wb ? OFF_WB1 : OFF_WB0) + W1_BYTES + (16 * (g4 & 1) + m16) * PW3 + 16 * (g4 >> 1);
-#ifdef DW_YOUNG_PRIO
-        if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);   // the later-dispatched wave of a SIMD otherwise loses every arbitration
-#endif
         dw.preamble();
         dw.run(pacc);
-#ifdef DW_YOUNG_PRIO
-        if (wave >= NW / 2) __builtin_amdgcn_s_setprio(0);
-#endif
     };
 
     // A workgroup keeps its band and walks over images blockIdx.y, blockIdx.y + gridDim.y, ...: the per-channel
