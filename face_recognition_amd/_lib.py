@@ -45,6 +45,7 @@ SIGNATURES = {
     "mfn_op_pw": (_I, [_I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "mfn_op_block": (_I, [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "mfn_op_gdconv7": (_I, [_I, _P, _P, _P, _P, _I, _I, _P]),
+    "mfn_op_tail": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "mfn_op_linear_l2norm": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fb_create": (_I, [C.POINTER(_P), _I, _P, _I, _L, _I, _I, _L]),
     "fb_fill": (_I, [_P, _L, _P, _I, _L]),

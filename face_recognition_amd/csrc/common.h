@@ -82,6 +82,10 @@ int launch_pw(int dt, const void* in, const void* w, const float* bias, const fl
               void* out, int64_t M, int K, int N, hipStream_t s);
 // 7x7 global depthwise conv: in T [B,49,C] -> out T [B,C]; w T [49][C]
 int launch_gdconv7(int dt, const void* in, const void* w, const float* bias, void* out, int B, int C, hipStream_t s);
+// fused tail: 1x1 conv 128 -> 512 + PReLU on the 7x7 map, then the 7x7 global depthwise conv (linear).
+// x T [B][49][128]; w6 T [512][128]; b6, s6 f32 [512] (s6 = PReLU slope MINUS ONE); w7 T [49][512]; b7 f32 [512]; out T [B][512]
+int launch_tail(int dt, const void* x, const void* w6, const float* b6, const float* s6, const void* w7, const float* b7,
+                void* out, int B, hipStream_t s);
 // embedding head: out f32 [B,E] = l2norm(in[B,K] . w[E,K]^T + bias)
 int launch_linear_l2norm(int dt, const void* in, const void* w, const float* bias, float* out, int B, int K, int E,
                          hipStream_t s);

@@ -13,7 +13,7 @@ namespace fra {
 
 static const double kBnEps = 1e-5;  // torch BatchNorm default, face_model.py:30,42,92
 
-enum OpKind { OP_STEM = 0, OP_DW = 1, OP_PW = 2, OP_GDCONV = 3, OP_LINEAR = 4, OP_BLOCK = 5, OP_STEMDW = 6 };
+enum OpKind { OP_STEM = 0, OP_DW = 1, OP_PW = 2, OP_GDCONV = 3, OP_LINEAR = 4, OP_BLOCK = 5, OP_STEMDW = 6, OP_TAIL = 7 };
 // per-image activation buffers inside the workspace
 enum Buf { BUF_X = -1, BUF_P0 = 0, BUF_P1 = 1, BUF_E = 2, BUF_D = 3, BUF_V = 4, BUF_OUT = 5, NBUF = 5 };
 static const int64_t kBufElems[NBUF] = {56 * 56 * 64, 56 * 56 * 64, 56 * 56 * 128, 28 * 28 * 128, 512};
@@ -39,6 +39,9 @@ struct Op {
     // OP_STEMDW only
     size_t sd_off[6] = {0, 0, 0, 0, 0, 0};          // wa, b1, s1, w2, b2, s2
     StemDwParams sp = {};
+    // OP_TAIL only: conv_6_sep weights / bias / slope - 1, conv_6_dw weights / bias
+    size_t tl_off[5] = {0, 0, 0, 0, 0};
+    const void* tl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 static const int NO_RESID = -100;
@@ -105,6 +108,11 @@ static void build_ops(mfn_handle* h, bool fused) {
                 o.bytes = px_in * 3 * 4 + px_out * 64 * es;
                 o.wbytes = 64 * 32 * es + 9 * 64 * es;
                 break;
+            case OP_TAIL:
+                o.flops = 2.0 * 49 * cin * cout + 2.0 * 49 * cout;
+                o.bytes = (49.0 * cin + cout) * es;
+                o.wbytes = ((double)cin * cout + 49.0 * cout) * es;
+                break;
         }
         ops.push_back(o);
     };
@@ -144,8 +152,12 @@ static void build_ops(mfn_handle* h, bool fused) {
     block("conv_45", 128, 512, 128, 2, false, 14);
     for (int i = 0; i < 2; ++i) block("conv_5.model." + std::to_string(i), 128, 256, 128, 1, true, 7);
     // face_model.py:88-92
-    add(OP_PW, "conv_6_sep", cur, BUF_E, NO_RESID, 128, 512, 7, 7, 1, true);
-    add(OP_GDCONV, "conv_6_dw", BUF_E, BUF_V, NO_RESID, 512, 512, 7, 1, 1, false);
+    if (fused) {
+        add(OP_TAIL, "conv_6_dw", cur, BUF_V, NO_RESID, 128, 512, 7, 1, 1, false);           // conv_6_sep + conv_6_dw
+    } else {
+        add(OP_PW, "conv_6_sep", cur, BUF_E, NO_RESID, 128, 512, 7, 7, 1, true);
+        add(OP_GDCONV, "conv_6_dw", BUF_E, BUF_V, NO_RESID, 512, 512, 7, 1, 1, false);
+    }
     add(OP_LINEAR, "linear", BUF_V, BUF_OUT, NO_RESID, 512, h->E, 1, 1, 1, false);
 }
 
@@ -238,6 +250,12 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
             for (int i = 0; i < 6; ++i) { o.sd_off[i] = off; off = align_up(off + sz[i], 256); }
             continue;
         }
+        if (o.kind == OP_TAIL) {
+            const size_t sz[5] = {(size_t)o.cin * o.cout * 2, (size_t)o.cout * 4, (size_t)o.cout * 4, 49 * (size_t)o.cout * 2,
+                                  (size_t)o.cout * 4};
+            for (int i = 0; i < 5; ++i) { o.tl_off[i] = off; off = align_up(off + sz[i], 256); }
+            continue;
+        }
         size_t wbytes = 0;
         switch (o.kind) {
             case OP_STEM: wbytes = 27 * 64 * 4; break;
@@ -247,6 +265,7 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
             case OP_LINEAR: wbytes = (size_t)o.cin * o.cout * 2; break;
             case OP_BLOCK: break;
             case OP_STEMDW: break;
+            case OP_TAIL: break;
         }
         o.w_off = off; off = align_up(off + wbytes, 256);
         o.bias_off = off; off = align_up(off + (size_t)o.cout * 4, 256);
@@ -283,6 +302,29 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
                 for (int t = 0; t < 9; ++t) w2[t * 64 + c] = to16(dt, (float)(w[c * 9 + t] * scale[c]));
                 b2[c] = (float)shift[c];
                 s2[c] = a[c] - 1.0f;
+            }
+            continue;
+        }
+        if (o.kind == OP_TAIL) {
+            const float* a;
+            uint16_t* w6 = reinterpret_cast<uint16_t*>(host.data() + o.tl_off[0]);
+            float* b6 = reinterpret_cast<float*>(host.data() + o.tl_off[1]);
+            float* s6 = reinterpret_cast<float*>(host.data() + o.tl_off[2]);
+            uint16_t* w7 = reinterpret_cast<uint16_t*>(host.data() + o.tl_off[3]);
+            float* b7 = reinterpret_cast<float*>(host.data() + o.tl_off[4]);
+            if ((rc = fetch(m, "conv_6_sep.conv.weight", (int64_t)C * o.cin, &w))) return rc;
+            if ((rc = bn_fold(m, "conv_6_sep.bn", C, scale, shift))) return rc;
+            if ((rc = fetch(m, "conv_6_sep.prelu.weight", C, &a))) return rc;
+            for (int oc = 0; oc < C; ++oc) {
+                for (int k = 0; k < o.cin; ++k) w6[(size_t)oc * o.cin + k] = to16(dt, (float)(w[(size_t)oc * o.cin + k] * scale[oc]));
+                b6[oc] = (float)shift[oc];
+                s6[oc] = a[oc] - 1.0f;
+            }
+            if ((rc = fetch(m, "conv_6_dw.conv.weight", (int64_t)C * 49, &w))) return rc;
+            if ((rc = bn_fold(m, "conv_6_dw.bn", C, scale, shift))) return rc;
+            for (int c = 0; c < C; ++c) {
+                for (int t = 0; t < 49; ++t) w7[(size_t)t * C + c] = to16(dt, (float)(w[(size_t)c * 49 + t] * scale[c]));
+                b7[c] = (float)shift[c];
             }
             continue;
         }
@@ -378,6 +420,10 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
             o.sp.s2 = reinterpret_cast<const float*>(base + o.sd_off[5]);
             continue;
         }
+        if (o.kind == OP_TAIL) {
+            for (int i = 0; i < 5; ++i) o.tl[i] = base + o.tl_off[i];
+            continue;
+        }
         if (o.kind == OP_BLOCK) {
             BlockParams& b = o.bp;
             b.cin = o.cin; b.cexp = o.cexp; b.cout = o.cout; b.h = o.hin; b.stride = o.stride; b.residual = o.residual;
@@ -441,6 +487,9 @@ static int run_op(const mfn_handle* h, const Op& o, const void* x, int x_is_u8, 
             return launch_block(h->dt, o.bp, buf(o.in), buf(o.out), b, s);
         case OP_STEMDW:
             return launch_stemdw(h->dt, o.sp, x, x_is_u8, n_src, buf(o.out), b, s);
+        case OP_TAIL:
+            return launch_tail(h->dt, buf(o.in), o.tl[0], (const float*)o.tl[1], (const float*)o.tl[2], o.tl[3],
+                               (const float*)o.tl[4], buf(o.out), b, s);
     }
     return FRA_ERR_ARG;
 }
@@ -650,6 +699,10 @@ int mfn_op_block(int dtype, int cin, int cexp, int cout, int h, int stride, int 
 int mfn_op_gdconv7(int dtype, const void* in, const void* w, const float* bias, void* out, int B, int C,
                    fra_stream stream) {
     return launch_gdconv7(dtype, in, w, bias, out, B, C, (hipStream_t)stream);
+}
+int mfn_op_tail(int dtype, const void* x, const void* w6, const float* b6, const float* s6, const void* w7,
+                const float* b7, void* out, int B, fra_stream stream) {
+    return launch_tail(dtype, x, w6, b6, s6, w7, b7, out, B, (hipStream_t)stream);
 }
 int mfn_op_linear_l2norm(int dtype, const void* in, const void* w, const float* bias, float* out, int B, int K, int E,
                          fra_stream stream) {

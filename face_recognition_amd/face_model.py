@@ -279,7 +279,7 @@ class MobileFaceNet(nn.Module):
         lib = _lib.load()
         if self._handle is None:
             raise RuntimeError("op_table: run a forward first")
-        kinds = ["stem", "dw3x3", "pw", "gdconv7", "linear", "block", "stemdw"]
+        kinds = ["stem", "dw3x3", "pw", "gdconv7", "linear", "block", "stemdw", "tail"]
         rows = []
         for i in range(lib.mfn_op_count(self._handle)):
             name = C.create_string_buffer(96)

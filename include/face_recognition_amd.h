@@ -127,6 +127,10 @@ int mfn_op_block(int dtype, int cin, int cexp, int cout, int h, int stride, int 
                  const float* s2p, const void* w3p, const float* b3, void* out, int B, fra_stream stream);
 int mfn_op_gdconv7(int dtype, const void* in, const void* w49xC, const float* bias, void* out, int B, int C,
                    fra_stream stream);
+/* conv_6_sep + conv_6_dw in one kernel (face_model.py:88-89): x [B][49][128] NHWC, w6 [512][128] (BN folded),
+ * b6 / s6 f32 [512] with s6 = PReLU slope - 1, w7 [49][512] tap-major, b7 f32 [512]; out [B][512]. */
+int mfn_op_tail(int dtype, const void* x, const void* w6, const float* b6, const float* s6_minus_1, const void* w7,
+                const float* b7, void* out, int B, fra_stream stream);
 int mfn_op_linear_l2norm(int dtype, const void* in, const void* wExK, const float* bias, float* out, int B, int K,
                          int E, fra_stream stream);
 

@@ -200,6 +200,31 @@ def test_gdconv7(device, dt, B):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("B", [1, 4, 7, 70])
+def test_fused_tail(device, dt, B):
+    """conv_6_sep (1x1 + PReLU) and conv_6_dw (7x7 global depthwise) in one kernel against the two torch convs."""
+    tdt, code, rel = DT[dt]
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn((B, 128, 7, 7), generator=g).to(tdt).float()
+    w6 = (torch.randn((512, 128), generator=g) / np.sqrt(128) * 1.3).to(tdt).float()
+    b6, s6 = torch.randn(512, generator=g) * 0.2, torch.rand(512, generator=g) * 0.3 + 0.1
+    w7 = (torch.randn((512, 1, 7, 7), generator=g) * 0.15).to(tdt).float()
+    b7 = torch.randn(512, generator=g) * 0.1
+    e = F.prelu(F.conv2d(x, w6[:, :, None, None], b6), s6)
+    ref = F.conv2d(e, w7, b7, 1, 0, 1, 512).reshape(B, 512)
+    dev = lambda t: t.contiguous().to(device)    # noqa: E731
+    xd = dev(x.permute(0, 2, 3, 1).to(tdt))
+    w6d, b6d, s6d = dev(w6.to(tdt)), dev(b6), dev(s6 - 1.0)
+    w7d, b7d = dev(w7.reshape(512, 49).t().to(tdt)), dev(b7)
+    out = torch.full((B, 512), float("nan"), dtype=tdt, device=device)
+    _lib.check(lib.mfn_op_tail(code, xd.data_ptr(), w6d.data_ptr(), b6d.data_ptr(), s6d.data_ptr(), w7d.data_ptr(),
+                               b7d.data_ptr(), out.data_ptr(), B, stream(device)), "tail")
+    torch.cuda.synchronize()
+    close(out, ref, 2 * rel, "fused tail")
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("B,E", [(1, 512), (33, 512), (64, 128), (5, 256), (40, 1024)])
 def test_linear_l2norm(device, dt, B, E):
     tdt, code, rel = DT[dt]

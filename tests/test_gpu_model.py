@@ -99,7 +99,7 @@ def test_fused_and_unfused_schedules_agree(hip_model, device, state_dict_np):
         assert len(hip_model.op_table()) == 50
     finally:
         hip_model.set_fused(True)
-    assert len(hip_model.op_table()) == 19
+    assert len(hip_model.op_table()) == 18
     want = ref.forward_numpy(state_dict_np, xn)
     assert cosine_rows(fused, want).min() >= COS_BAR and cosine_rows(plain, want).min() >= COS_BAR
     assert cosine_rows(fused, plain).min() >= 0.99999
