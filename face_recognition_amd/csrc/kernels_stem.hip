@@ -96,7 +96,7 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, const T* __restrict__
     constexpr int H = 56, W = 56, HI = 112;
     constexpr int RIN = TR + 2, PITCH = SD_PITCH;
     constexpr int PIN = RIN * W, POUT = TR * W;
-    constexpr int MTI = (PIN + 31) / 32, MTO = (POUT + 31) / 32;
+    constexpr int MTI = (PIN + 31) / 32;
     constexpr int MTIW = (MTI + NW - 1) / NW;
     static_assert(W % 8 == 0 && W / 8 <= NW && PITCH >= W + 2, "depthwise stage: one wave per 8-pixel column group");
     constexpr int ES_BYTES = RIN * PITCH * 128;
