@@ -95,7 +95,7 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, const T* __restrict__
     constexpr int NT = NW * 64;
     constexpr int H = 56, W = 56, HI = 112;
     constexpr int RIN = TR + 2, PITCH = SD_PITCH;
-    constexpr int PIN = RIN * W, POUT = TR * W;
+    constexpr int PIN = RIN * W;
     constexpr int MTI = (PIN + 31) / 32;
     constexpr int MTIW = (MTI + NW - 1) / NW;
     static_assert(W % 8 == 0 && W / 8 <= NW && PITCH >= W + 2, "depthwise stage: one wave per 8-pixel column group");
