@@ -298,6 +298,20 @@ def main():
         "forward_tflops": round(faces_per_s * 2 * layers.macs_per_face(512) / 1e12, 2),
     }
 
+    if rank == 0 and not args.no_latency:
+        # the optional call shapes of the same forward (not `value`): raw uint8 HWC crops, and flip-TTA embeddings
+        xu8 = torch.randint(0, 256, (B, 112, 112, 3), generator=g, device=dev, dtype=torch.uint8)
+        extra = {}
+        for name, fn in (("u8_hwc_input", lambda: net.forward_u8(xu8)), ("u8_hwc_input_flip_tta", lambda: net.forward_u8(xu8, tta=True))):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            torch.cuda.synchronize()
+            extra[name] = {"faces_per_s": round(B * args.steps / (time.perf_counter() - t1), 1)}
+        result["other_call_shapes"] = extra
     if rank == 0:
         groups, total_ms = per_kernel_profile(net, x, 3, args.dtype)
         dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
