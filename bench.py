@@ -228,6 +228,36 @@ def verification_timing(dev):
             "accuracy": round(float(a_dev.mean()) * 100, 3)}
 
 
+def verification_12k(net, dev, pairs=12000, batch=256):
+    """BASELINE configs[1], second half: 12k synthetic verification pairs through getFeature (flip-TTA: four
+    crop sets per batch, one forward for all four) and the 10-fold protocol on the device.  Same-pairs are two
+    noisy copies of one template, different-pairs two templates; crops are resident in HBM, as `value`'s are."""
+    from face_recognition_amd import Evaluation
+    ds = synthetic.PairSet(pairs)
+    flags = torch.tensor(ds.flags, device=dev).view(-1, 1, 1, 1)
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    up = lambda t: t.repeat_interleave(8, 2).repeat_interleave(8, 3)    # noqa: E731
+    t1 = up(torch.rand((pairs, 3, 14, 14), generator=g, device=dev) * 2 - 1)
+    t2 = up(torch.rand((pairs, 3, 14, 14), generator=g, device=dev) * 2 - 1)
+    left = t1 + 0.3 * torch.randn(t1.shape, generator=g, device=dev)
+    right = torch.where(flags == 1, t1, t2) + 0.3 * torch.randn(t1.shape, generator=g, device=dev)
+    del t1, t2
+    lf, rf = torch.flip(left, dims=[3]), torch.flip(right, dims=[3])
+    loader = [[left[i:i + batch], lf[i:i + batch], right[i:i + batch], rf[i:i + batch]] for i in range(0, pairs, batch)]
+    Evaluation.getFeature(net, loader[:2], dev, flip=True, keep_on_device=True)      # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fl, fr = Evaluation.getFeature(net, loader, dev, flip=True, keep_on_device=True)
+    torch.cuda.synchronize()
+    t1_ = time.perf_counter()
+    accs, thr = Evaluation.evaluation_10_fold(fl, fr, ds, "cos_distance")
+    t2_ = time.perf_counter()
+    return {"pairs": pairs, "crops_embedded": 4 * pairs, "embed_s": round(t1_ - t0, 4),
+            "faces_per_s": round(4 * pairs / (t1_ - t0), 1), "protocol_10fold_ms": round((t2_ - t1_) * 1e3, 1),
+            "accuracy": round(float(np.mean(accs)) * 100, 3), "threshold": round(float(np.mean(thr)), 4)}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -337,6 +367,7 @@ def main():
         if not args.no_latency:
             result["latency_us"] = latency(net, dev)
             result["verification_10fold"] = verification_timing(dev)
+            result["verification_12k_pairs"] = verification_12k(net, dev)
     if not args.no_search:
         s = run_search(args, rank, world, dev, dist)
         if rank == 0:
