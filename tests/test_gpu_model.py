@@ -227,3 +227,25 @@ def test_prepare_facebank_from_image_folders(hip_model, device, state_dict_np, t
     q = hip_model.forward_u8(torch.from_numpy(people["bob"]).to(device), tta=True)
     mn, idx, _ = match_facebank(q, emb, threshold=60)
     assert names[int(idx[0]) + 1] == "bob" and float(mn[0]) < 1e-3
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the contract's keys (a short run: small batch, no search / CPU leg)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "64",
+                        "--no-search", "--no-cpu", "--no-latency"], capture_output=True, text=True, timeout=280, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in r, key
+    assert r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1 and r["unit"] == "faces/s" and r["value"] > 0
+    assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None and "workload" in r["config"]
+    rf = r["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
