@@ -122,18 +122,20 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, const T* __restrict__
     // ---- prologue.  Every global load of the prologue is issued before the first use of any of them, so the
     // workgroup pays one memory latency, not one per loop; the LDS zeroing runs while they are in flight.
     // Input band: column group g holds input columns 4(g-1) .. 4(g-1)+3 (g = 0 and g = NG-1 are padding).
-    constexpr int NIN = U8 ? NR * NG : 3 * NR * NG;         // staging items: 4 pixels of one row (x 3 channels for U8)
-    constexpr int IN_IT = (NIN + NT - 1) / NT;
+    // staging items: 4 pixels of one row (x 3 channels for U8).  Half a wave (32 lanes, 30 used) takes one row of
+    // column groups, NT / 32 rows per pass: shifts and masks instead of divisions by 30 and 13
+    constexpr int NROWS = U8 ? NR : 3 * NR, ROWS_PER_PASS = NT / 32;
+    constexpr int IN_IT = (NROWS + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+    static_assert(NG <= 32 && 3 * NR <= 3 * ROWS_PER_PASS, "staging map");
     f32x4 vin[U8 ? 1 : IN_IT];
     unsigned win[U8 ? IN_IT : 1][3];
     bool in_ok[IN_IT];
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
-        const int i = tid + it * NT;
-        const int g = i % NG, cr = i / NG;                   // cr = c * NR + ry (fp32) or ry (uint8)
-        const int ry = U8 ? cr : cr % NR, c = U8 ? 0 : cr / NR;
+        const int g = tid & 31, cr = (tid >> 5) + ROWS_PER_PASS * it;   // cr = c * NR + ry (fp32) or ry (uint8)
+        const int c = U8 ? 0 : (cr >= NR) + (cr >= 2 * NR), ry = cr - c * NR;
         const int yin = rin0 + ry;
-        in_ok[it] = i < NIN && g >= 1 && g <= 28 && yin >= 0 && yin < HI;
+        in_ok[it] = cr < NROWS && g >= 1 && g <= 28 && yin >= 0 && yin < HI;
         const int x0 = flip ? 108 - 4 * (g - 1) : 4 * (g - 1);
         if (!U8) {
             vin[it] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -172,9 +174,8 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, const T* __restrict__
     }
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
-        const int i = tid + it * NT;
-        if (i >= NIN) continue;
-        const int g = i % NG, cr = i / NG;
+        const int g = tid & 31, cr = (tid >> 5) + ROWS_PER_PASS * it;
+        if (cr >= NROWS || g >= NG) continue;
         if (!U8) {
             f32x4 v = vin[it];
             if (flip) v = f32x4{v[3], v[2], v[1], v[0]};
@@ -216,9 +217,9 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, const T* __restrict__
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int t = 16 * s + 8 * h + j;
-            const int c = t / 9, rem = t - 9 * c, ky = rem / 3, kx = rem - 3 * ky;
-            toff[s][j] = (c * NR + ky) * PW + kx + 3;
+            // both halves' values are compile-time constants: one select instead of two divisions per tap
+            auto off = [](int t) { const int c = t / 9, rem = t - 9 * c, ky = rem / 3, kx = rem - 3 * ky; return (c * NR + ky) * PW + kx + 3; };
+            toff[s][j] = h ? off(16 * s + 8 + j) : off(16 * s + j);
         }
     __syncthreads();
 
