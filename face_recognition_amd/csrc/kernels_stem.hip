@@ -126,7 +126,7 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, const T* __restrict__
     // column groups, NT / 32 rows per pass: shifts and masks instead of divisions by 30 and 13
     constexpr int NROWS = U8 ? NR : 3 * NR, ROWS_PER_PASS = NT / 32;
     constexpr int IN_IT = (NROWS + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
-    static_assert(NG <= 32 && 3 * NR <= 3 * ROWS_PER_PASS, "staging map");
+    static_assert(NG <= 32, "staging map: one row of column groups per half wave");
     f32x4 vin[U8 ? 1 : IN_IT];
     unsigned win[U8 ? IN_IT : 1][3];
     bool in_ok[IN_IT];
