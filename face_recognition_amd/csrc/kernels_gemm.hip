@@ -114,23 +114,25 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const T* __restrict__ A, c
 // ---------------------------------------------------------------------------------------------
 // Embedding head: out f32 [B,E] = l2norm(in[B,512] . w[E,512]^T + bias[E]).
 //   (Flatten + Linear + BatchNorm1d folded + l2_norm: face_model.py:124-129, 19-22)
-//   32 images per block; wave w owns channels [w E/4, (w+1) E/4); the squared row norm is
-//   reduced over registers, the two lane halves and the four waves.
+//   32 images per block; NWV waves, wave w owns channels [w E/NWV, (w+1) E/NWV); the squared row norm is
+//   reduced over registers, the two lane halves and the waves (in wave order, whatever the batch).  One
+//   32-channel tile per wave where the block size allows: a block streams the whole weight matrix
+//   through one CU, and at batch 1 that stream (a chain of dependent loads per wave) is all there is.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NTW>
-__global__ __launch_bounds__(256) void linear_l2norm_kernel(const T* __restrict__ A, const T* __restrict__ Wt,
+template <typename T, int NWV, int NTW>
+__global__ __launch_bounds__(NWV * 64) void linear_l2norm_kernel(const T* __restrict__ A, const T* __restrict__ Wt,
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ out, int B) {
     typedef typename vec8<T>::type V8;
-    constexpr int K = 512, CH = K / 8, E = 128 * NTW;
+    constexpr int K = 512, CH = K / 8, E = 32 * NWV * NTW, NT = NWV * 64;
     __shared__ __attribute__((aligned(16))) char smem[32 * K * 2];
-    __shared__ float red[4][32];
+    __shared__ float red[NWV][32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int b0 = blockIdx.x * 32;
 
-    for (int i = tid; i < 32 * CH; i += 256) {
+    for (int i = tid; i < 32 * CH; i += NT) {
         const int row = i / CH, c = i - row * CH;
         int gb = b0 + row;
         gb = gb < B ? gb : B - 1;
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void linear_l2norm_kernel(const T* __restrict_
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[nt][g] = 0.0f;
     const int nbase = wave * 32 * NTW;
-#pragma unroll 4
+#pragma unroll 8
     for (int s = 0; s < K / 16; ++s) {
         const int c = 2 * s + h;
         const V8 bfrag = *reinterpret_cast<const V8*>(smem + ((r * CH + (c ^ swz<CH>(r))) << 4));
@@ -167,7 +169,10 @@ __global__ __launch_bounds__(256) void linear_l2norm_kernel(const T* __restrict_
     ss += __shfl_xor(ss, 32, 64);
     if (h == 0) red[wave][r] = ss;
     __syncthreads();
-    const float nrm = sqrtf(red[0][r] + red[1][r] + red[2][r] + red[3][r]);
+    float tot = red[0][r];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) tot += red[w][r];
+    const float nrm = sqrtf(tot);
     const int b = b0 + r;
     if (b < B) {
 #pragma unroll
@@ -230,12 +235,12 @@ int launch_pw(int dt, const void* in, const void* w, const float* bias, const fl
 
 template <typename T>
 static int launch_linear_t(const T* in, const T* w, const float* bias, float* out, int B, int E, hipStream_t s) {
-    const dim3 grid((B + 31) / 32), block(256);
+    const dim3 grid((B + 31) / 32);
     switch (E) {
-        case 128: hipLaunchKernelGGL((linear_l2norm_kernel<T, 1>), grid, block, 0, s, in, w, bias, out, B); break;
-        case 256: hipLaunchKernelGGL((linear_l2norm_kernel<T, 2>), grid, block, 0, s, in, w, bias, out, B); break;
-        case 512: hipLaunchKernelGGL((linear_l2norm_kernel<T, 4>), grid, block, 0, s, in, w, bias, out, B); break;
-        case 1024: hipLaunchKernelGGL((linear_l2norm_kernel<T, 8>), grid, block, 0, s, in, w, bias, out, B); break;
+        case 128: hipLaunchKernelGGL((linear_l2norm_kernel<T, 4, 1>), grid, dim3(256), 0, s, in, w, bias, out, B); break;
+        case 256: hipLaunchKernelGGL((linear_l2norm_kernel<T, 8, 1>), grid, dim3(512), 0, s, in, w, bias, out, B); break;
+        case 512: hipLaunchKernelGGL((linear_l2norm_kernel<T, 16, 1>), grid, dim3(1024), 0, s, in, w, bias, out, B); break;
+        case 1024: hipLaunchKernelGGL((linear_l2norm_kernel<T, 16, 2>), grid, dim3(1024), 0, s, in, w, bias, out, B); break;
         default:
             FRA_REQUIRE(false, FRA_ERR_ARG, "linear: embedding_size %d unsupported (128, 256, 512, 1024)", E);
     }
