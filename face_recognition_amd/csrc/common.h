@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/face_recognition_amd.h"  // status codes and dtype tags (global namespace)
 
 namespace fra {
@@ -67,6 +69,21 @@ const char* last_error();
             return code;                                                                       \
         }                                                                                      \
     } while (0)
+
+// A kernel's dynamic-LDS limit is a property of the kernel ON ONE DEVICE: raise it the first time the kernel
+// is launched on each device of the process (bit d of `done` = device d has it; devices past 63 set it on
+// every launch).  *device, if given, receives the current device.
+inline int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done, int* device = nullptr) {
+    int dev = 0;
+    FRA_HIP(hipGetDevice(&dev));
+    const bool known = dev < 64 && ((done.load(std::memory_order_acquire) >> dev) & 1);
+    if (!known) {
+        FRA_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    if (device) *device = dev;
+    return FRA_OK;
+}
 
 // ---- kernel launchers (device pointers, parameters already in kernel layout) ------------------
 // All return a Status; all launch on `s` and never synchronise.

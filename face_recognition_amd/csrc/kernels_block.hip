@@ -628,13 +628,15 @@ static int launch_block_cfg(const BlockParams& p, const void* x, void* out, int 
     const int bands = (H / S) / TR;
     constexpr int lds = block_lds_bytes<CIN, CEXP, COUT, H, S, TR, MODE>();
     auto kern = block_kernel<T, CIN, CEXP, COUT, H, S, TR, RESID, NW, MINW, MODE>;
-    static bool attr_done = false;   // per instantiation
-    static int slots = 1;            // resident workgroups per band (of the device first used; one process drives one GPU)
-    if (!attr_done) {
-        FRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    static std::atomic<uint64_t> lds_set;      // per instantiation: devices whose LDS limit is raised
+    static std::atomic<int> slots_of[64];      // resident workgroups per band, per device (0 = not asked yet)
+    int dev = 0;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set, &dev)) return rc;
+    int slots = dev < 64 ? slots_of[dev].load(std::memory_order_relaxed) : 0;
+    if (slots == 0) {
         slots = resident_workgroups(reinterpret_cast<const void*>(kern), NW * 64, lds) / bands;
         if (slots < 1) slots = 1;
-        attr_done = true;
+        if (dev < 64) slots_of[dev].store(slots, std::memory_order_relaxed);
     }
     int groups = B;
     if (PERSIST) {

@@ -299,11 +299,8 @@ template <typename T, bool U8, int TR, int NW, int MINW>
 static int launch_stemdw_cfg(const StemDwParams& p, const void* x, int n_src, void* out, int B, hipStream_t s) {
     constexpr int lds = (TR + 2) * SD_PITCH * 128 + 4 * (2 * TR + 5) * 120 * 2 + 9 * 64 * 2 + 4 * 256;
     auto kern = stemdw_kernel<T, U8, TR, NW, MINW>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        FRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> lds_set;   // per instantiation: devices whose LDS limit is raised
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set)) return rc;
     hipLaunchKernelGGL(kern, dim3(56 / TR, B), dim3(NW * 64), lds, s, x, n_src, (const T*)p.wa, p.b1, p.s1, (const T*)p.w2,
                        p.b2, p.s2, (T*)out);
     FRA_HIP(hipGetLastError());

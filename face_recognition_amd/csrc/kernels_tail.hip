@@ -92,18 +92,12 @@ int fra::launch_tail(int dt, const void* x, const void* w6, const float* b6, con
     FRA_REQUIRE(x && w6 && b6 && s6 && w7 && b7 && out, FRA_ERR_ARG, "tail: null pointer");
     FRA_REQUIRE(B > 0, FRA_ERR_ARG, "tail: batch %d", B);
     const dim3 grid((B + TAIL_IMG - 1) / TAIL_IMG), block(TAIL_NW * 64);
-    static bool attr_done[2] = {false, false};
+    static std::atomic<uint64_t> lds_set[2];
     if (dt == ACT_F16) {
-        if (!attr_done[0]) {
-            FRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS));
-            attr_done[0] = true;
-        }
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(tail_kernel<f16>), TAIL_LDS, lds_set[0])) return rc;
         hipLaunchKernelGGL(tail_kernel<f16>, grid, block, TAIL_LDS, s, (const f16*)x, (const f16*)w6, b6, s6, (const f16*)w7, b7, (f16*)out, B);
     } else if (dt == ACT_BF16) {
-        if (!attr_done[1]) {
-            FRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS));
-            attr_done[1] = true;
-        }
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(tail_kernel<bf16>), TAIL_LDS, lds_set[1])) return rc;
         hipLaunchKernelGGL(tail_kernel<bf16>, grid, block, TAIL_LDS, s, (const bf16*)x, (const bf16*)w6, b6, s6, (const bf16*)w7, b7, (bf16*)out, B);
     } else {
         FRA_REQUIRE(false, FRA_ERR_ARG, "tail: unsupported activation dtype %d", dt);
