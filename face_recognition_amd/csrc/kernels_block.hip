@@ -70,6 +70,7 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 //              at p == 4 after the PReLU: slope(q+1), then for q odd the project loop
 //              { WAIT fragment n; two MFMAs; issue fragment n + 4 }.
 // dw_outstanding() replays that order and returns the number of reads issued after the awaited one.
+constexpr int BLOCK_FEW_IMAGES = 8;   // batches up to this size run the short-band configurations
 constexpr int DW_STEPS = 20, DW_PD = 2, DW_RING = DW_PD + 1;   // reads run DW_PD steps ahead (3 measured no faster)
 constexpr int dw_outstanding(int nt16, int kind, int st, int n) {   // kind 0: taps(st); kind 1: fragment n in step st
     int issued = 7;
@@ -650,22 +651,32 @@ static int launch_block_cfg(const BlockParams& p, const void* x, void* out, int 
     return FRA_OK;
 }
 
+// Two band heights per shape.  The tall one has the least halo work and is what a full batch runs; with only a
+// few images it would leave most of the chip idle (conv_4 as whole-image bands: ONE workgroup per image), so
+// small batches run short bands: more redundant expand rows, but 7 to 14 workgroups per image side by side.
 template <typename T>
 static int launch_block_t(const BlockParams& p, const void* x, void* out, int B, hipStream_t s) {
     const int key = p.cin * 1000000 + p.cexp * 1000 + p.h * 10 + p.stride;
+    const bool few = B <= BLOCK_FEW_IMAGES;
     switch (key) {
         case 64 * 1000000 + 128 * 1000 + 56 * 10 + 2:   // conv_23
-            return launch_block_cfg<T, 64, 128, 64, 56, 2, 4, false, 8, 2, 1, true>(p, x, out, B, s);
+            return few ? launch_block_cfg<T, 64, 128, 64, 56, 2, 2, false, 8, 2, 1, true>(p, x, out, B, s)
+                       : launch_block_cfg<T, 64, 128, 64, 56, 2, 4, false, 8, 2, 1, true>(p, x, out, B, s);
         case 64 * 1000000 + 128 * 1000 + 28 * 10 + 1:   // conv_3.*
-            return launch_block_cfg<T, 64, 128, 64, 28, 1, 7, true, 8, 2, 1, true>(p, x, out, B, s);
+            return few ? launch_block_cfg<T, 64, 128, 64, 28, 1, 2, true, 8, 2, 1, true>(p, x, out, B, s)
+                       : launch_block_cfg<T, 64, 128, 64, 28, 1, 7, true, 8, 2, 1, true>(p, x, out, B, s);
         case 64 * 1000000 + 256 * 1000 + 28 * 10 + 2:   // conv_34
-            return launch_block_cfg<T, 64, 256, 128, 28, 2, 7, false, 8, 2, 1, true>(p, x, out, B, s);
+            return few ? launch_block_cfg<T, 64, 256, 128, 28, 2, 2, false, 8, 2, 1, true>(p, x, out, B, s)
+                       : launch_block_cfg<T, 64, 256, 128, 28, 2, 7, false, 8, 2, 1, true>(p, x, out, B, s);
         case 128 * 1000000 + 256 * 1000 + 14 * 10 + 1:  // conv_4.*
-            return launch_block_cfg<T, 128, 256, 128, 14, 1, 14, true, 8, 2, 1, true>(p, x, out, B, s);
+            return few ? launch_block_cfg<T, 128, 256, 128, 14, 1, 2, true, 8, 2, 1, true>(p, x, out, B, s)
+                       : launch_block_cfg<T, 128, 256, 128, 14, 1, 14, true, 8, 2, 1, true>(p, x, out, B, s);
         case 128 * 1000000 + 512 * 1000 + 14 * 10 + 2:  // conv_45
-            return launch_block_cfg<T, 128, 512, 128, 14, 2, 7, false, 8, 2, 1, true>(p, x, out, B, s);
+            return few ? launch_block_cfg<T, 128, 512, 128, 14, 2, 1, false, 8, 2, 1, true>(p, x, out, B, s)
+                       : launch_block_cfg<T, 128, 512, 128, 14, 2, 7, false, 8, 2, 1, true>(p, x, out, B, s);
         case 128 * 1000000 + 256 * 1000 + 7 * 10 + 1:   // conv_5.*
-            return launch_block_cfg<T, 128, 256, 128, 7, 1, 7, true, 8, 2, 1, true>(p, x, out, B, s);
+            return few ? launch_block_cfg<T, 128, 256, 128, 7, 1, 1, true, 8, 2, 1, true>(p, x, out, B, s)
+                       : launch_block_cfg<T, 128, 256, 128, 7, 1, 7, true, 8, 2, 1, true>(p, x, out, B, s);
         default: break;
     }
     FRA_REQUIRE(false, FRA_ERR_ARG, "block: no fused kernel for cin=%d cexp=%d h=%d stride=%d", p.cin, p.cexp, p.h,

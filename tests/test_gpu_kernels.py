@@ -122,12 +122,16 @@ def _w3_image(w3pos, cout):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("many", [False, True])
 @pytest.mark.parametrize("cin,cexp,cout,H,stride,res,B", [(64, 128, 64, 56, 2, False, 2), (64, 128, 64, 28, 1, True, 3),
                                                          (64, 256, 128, 28, 2, False, 2), (128, 256, 128, 14, 1, True, 3),
                                                          (128, 512, 128, 14, 2, False, 2), (128, 256, 128, 7, 1, True, 5)])
-def test_fused_block(device, dt, cin, cexp, cout, H, stride, res, B):
+def test_fused_block(device, dt, cin, cexp, cout, H, stride, res, B, many):
     """Fused expand/depthwise/project block against the three torch convs on 16-bit-rounded operands;
-    the intermediate tensors are rounded to the storage type where the kernel rounds them."""
+    the intermediate tensors are rounded to the storage type where the kernel rounds them.  The library runs
+    batches of up to 8 images with short bands and larger ones with tall bands: both are covered."""
+    if many:
+        B += 8
     tdt, code, rel = DT[dt]
     lib = _lib.load()
     g = torch.Generator().manual_seed(11)
