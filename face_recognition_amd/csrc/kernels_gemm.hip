@@ -118,28 +118,36 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const T* __restrict__ A, c
 //   reduced over registers, the two lane halves and the waves (in wave order, whatever the batch).  One
 //   32-channel tile per wave where the block size allows: a block streams the whole weight matrix
 //   through one CU, and at batch 1 that stream (a chain of dependent loads per wave) is all there is.
+//   SPLIT (a single group of up to 32 images): the same waves as NWV one-wave blocks (blockIdx.y = wave), so
+//   that the weight matrix streams through NWV compute units at once; such a block cannot see the other
+//   channels' squares, writes its values un-normalised, and l2norm_replay_kernel finishes the rows with the
+//   same additions in the same order -- the result does not depend on which way a batch went.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NWV, int NTW>
-__global__ __launch_bounds__(NWV * 64) void linear_l2norm_kernel(const T* __restrict__ A, const T* __restrict__ Wt,
-                                                            const float* __restrict__ bias,
-                                                            float* __restrict__ out, int B) {
+template <typename T, int NWV, int NTW, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 64 : NWV * 64) void linear_l2norm_kernel(const T* __restrict__ A,
+                                                                            const T* __restrict__ Wt,
+                                                                            const float* __restrict__ bias,
+                                                                            float* __restrict__ out, int B) {
     typedef typename vec8<T>::type V8;
     constexpr int K = 512, CH = K / 8, E = 32 * NWV * NTW, NT = NWV * 64;
-    __shared__ __attribute__((aligned(16))) char smem[32 * K * 2];
-    __shared__ float red[NWV][32];
+    __shared__ __attribute__((aligned(16))) char smem[SPLIT ? 16 : 32 * K * 2];
+    __shared__ float red[SPLIT ? 1 : NWV][32];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = SPLIT ? blockIdx.y : tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int b0 = blockIdx.x * 32;
+    const T* arow = A + (size_t)(b0 + r < B ? b0 + r : B - 1) * K + 8 * h;   // SPLIT: fragments straight from memory
 
-    for (int i = tid; i < 32 * CH; i += NT) {
-        const int row = i / CH, c = i - row * CH;
-        int gb = b0 + row;
-        gb = gb < B ? gb : B - 1;
-        const V8 v = *reinterpret_cast<const V8*>(A + (size_t)gb * K + c * 8);
-        *reinterpret_cast<V8*>(smem + ((row * CH + (c ^ swz<CH>(row))) << 4)) = v;
+    if constexpr (!SPLIT) {
+        for (int i = tid; i < 32 * CH; i += NT) {
+            const int row = i / CH, c = i - row * CH;
+            int gb = b0 + row;
+            gb = gb < B ? gb : B - 1;
+            const V8 v = *reinterpret_cast<const V8*>(A + (size_t)gb * K + c * 8);
+            *reinterpret_cast<V8*>(smem + ((row * CH + (c ^ swz<CH>(row))) << 4)) = v;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     f32x16 acc[NTW];
 #pragma unroll
@@ -147,10 +155,13 @@ __global__ __launch_bounds__(NWV * 64) void linear_l2norm_kernel(const T* __rest
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[nt][g] = 0.0f;
     const int nbase = wave * 32 * NTW;
-#pragma unroll 8
+    constexpr int UNR = SPLIT ? 32 : 8;   // SPLIT: every load of the wave's stream in flight at once
+#pragma unroll UNR
     for (int s = 0; s < K / 16; ++s) {
         const int c = 2 * s + h;
-        const V8 bfrag = *reinterpret_cast<const V8*>(smem + ((r * CH + (c ^ swz<CH>(r))) << 4));
+        V8 bfrag;
+        if constexpr (SPLIT) bfrag = *reinterpret_cast<const V8*>(arow + 16 * s);
+        else bfrag = *reinterpret_cast<const V8*>(smem + ((r * CH + (c ^ swz<CH>(r))) << 4));
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const V8 afrag = *reinterpret_cast<const V8*>(Wt + (size_t)(nbase + nt * 32 + r) * K + s * 16 + h * 8);
@@ -166,13 +177,16 @@ __global__ __launch_bounds__(NWV * 64) void linear_l2norm_kernel(const T* __rest
             acc[nt][g] = v;
             ss = fmaf(v, v, ss);
         }
-    ss += __shfl_xor(ss, 32, 64);
-    if (h == 0) red[wave][r] = ss;
-    __syncthreads();
-    float tot = red[0][r];
+    float nrm = 1.0f;
+    if constexpr (!SPLIT) {
+        ss += __shfl_xor(ss, 32, 64);
+        if (h == 0) red[wave][r] = ss;
+        __syncthreads();
+        float tot = red[0][r];
 #pragma unroll
-    for (int w = 1; w < NWV; ++w) tot += red[w][r];
-    const float nrm = sqrtf(tot);
+        for (int w = 1; w < NWV; ++w) tot += red[w][r];
+        nrm = sqrtf(tot);
+    }
     const int b = b0 + r;
     if (b < B) {
 #pragma unroll
@@ -181,10 +195,38 @@ __global__ __launch_bounds__(NWV * 64) void linear_l2norm_kernel(const T* __rest
             for (int q = 0; q < 4; ++q) {
                 f32x4 o;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = acc[nt][4 * q + i] / nrm;
+                for (int i = 0; i < 4; ++i) o[i] = SPLIT ? acc[nt][4 * q + i] : acc[nt][4 * q + i] / nrm;
                 *reinterpret_cast<f32x4*>(out + (size_t)b * E + nbase + nt * 32 + 8 * q + 4 * h) = o;
             }
     }
+}
+
+// Finishes linear_l2norm_kernel<.., SPLIT>: row b of out [B][E] holds the un-normalised values.  One wave per row;
+// lane 2 w + h replays what half h of wave w adds up in the un-split kernel (its tiles in order, its 16 rows of a
+// tile in register order), the halves are added, the waves summed in wave order, and every value is divided by
+// the root of that sum -- bit for bit what the un-split kernel writes.
+template <int NWV, int NTW>
+__global__ __launch_bounds__(64) void l2norm_replay_kernel(float* __restrict__ out) {
+    constexpr int E = 32 * NWV * NTW;
+    static_assert(2 * NWV <= 64, "one lane per (wave, half)");
+    float* row = out + (size_t)blockIdx.x * E;
+    const int lane = threadIdx.x, w = lane >> 1, h = lane & 1;
+    float ss = 0.0f;
+    if (w < NWV) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float v = row[(w * NTW + nt) * 32 + acc_row(g, h)];
+                ss = fmaf(v, v, ss);
+            }
+    }
+    ss += __shfl_xor(ss, 1, 64);
+    float tot = __shfl(ss, 0, 64);
+#pragma unroll
+    for (int i = 1; i < NWV; ++i) tot += __shfl(ss, 2 * i, 64);
+    const float nrm = sqrtf(tot);
+    for (int j = lane; j < E; j += 64) row[j] = row[j] / nrm;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -236,14 +278,22 @@ int launch_pw(int dt, const void* in, const void* w, const float* bias, const fl
 template <typename T>
 static int launch_linear_t(const T* in, const T* w, const float* bias, float* out, int B, int E, hipStream_t s) {
     const dim3 grid((B + 31) / 32);
+#define FRA_LINEAR(NWV, NTW)                                                                                        \
+    if (B <= 32) {                                                                                                  \
+        hipLaunchKernelGGL((linear_l2norm_kernel<T, NWV, NTW, true>), dim3(1, NWV), dim3(64), 0, s, in, w, bias, out, B); \
+        hipLaunchKernelGGL((l2norm_replay_kernel<NWV, NTW>), dim3(B), dim3(64), 0, s, out);                           \
+    } else {                                                                                                        \
+        hipLaunchKernelGGL((linear_l2norm_kernel<T, NWV, NTW, false>), grid, dim3(NWV * 64), 0, s, in, w, bias, out, B); \
+    }
     switch (E) {
-        case 128: hipLaunchKernelGGL((linear_l2norm_kernel<T, 4, 1>), grid, dim3(256), 0, s, in, w, bias, out, B); break;
-        case 256: hipLaunchKernelGGL((linear_l2norm_kernel<T, 8, 1>), grid, dim3(512), 0, s, in, w, bias, out, B); break;
-        case 512: hipLaunchKernelGGL((linear_l2norm_kernel<T, 16, 1>), grid, dim3(1024), 0, s, in, w, bias, out, B); break;
-        case 1024: hipLaunchKernelGGL((linear_l2norm_kernel<T, 16, 2>), grid, dim3(1024), 0, s, in, w, bias, out, B); break;
+        case 128: FRA_LINEAR(4, 1) break;
+        case 256: FRA_LINEAR(8, 1) break;
+        case 512: FRA_LINEAR(16, 1) break;
+        case 1024: FRA_LINEAR(16, 2) break;
         default:
             FRA_REQUIRE(false, FRA_ERR_ARG, "linear: embedding_size %d unsupported (128, 256, 512, 1024)", E);
     }
+#undef FRA_LINEAR
     FRA_HIP(hipGetLastError());
     return FRA_OK;
 }

@@ -42,8 +42,9 @@ __global__ __launch_bounds__(TAIL_NW * 64) void tail_kernel(const T* __restrict_
     }
     __syncthreads();
 
+    // gridDim.y workgroups share the channel tiles of a group of faces (small batches: more compute units at work)
 #pragma unroll 1
-    for (int ct = wave; ct < TAIL_C / 32; ct += TAIL_NW) {
+    for (int ct = wave + TAIL_NW * blockIdx.y; ct < TAIL_C / 32; ct += TAIL_NW * gridDim.y) {
         const int ch = 32 * ct + r;                              // this lane's output channel
         V8 wb[TAIL_K / 16];
 #pragma unroll
@@ -91,7 +92,8 @@ int fra::launch_tail(int dt, const void* x, const void* w6, const float* b6, con
                      const float* b7, void* out, int B, hipStream_t s) {
     FRA_REQUIRE(x && w6 && b6 && s6 && w7 && b7 && out, FRA_ERR_ARG, "tail: null pointer");
     FRA_REQUIRE(B > 0, FRA_ERR_ARG, "tail: batch %d", B);
-    const dim3 grid((B + TAIL_IMG - 1) / TAIL_IMG), block(TAIL_NW * 64);
+    const int groups = (B + TAIL_IMG - 1) / TAIL_IMG;
+    const dim3 grid(groups, groups <= 8 ? TAIL_C / 32 / TAIL_NW : 1), block(TAIL_NW * 64);
     static std::atomic<uint64_t> lds_set[2];
     if (dt == ACT_F16) {
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(tail_kernel<f16>), TAIL_LDS, lds_set[0])) return rc;

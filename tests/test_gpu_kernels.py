@@ -248,6 +248,25 @@ def test_linear_l2norm(device, dt, B, E):
     assert torch.allclose(out.cpu().norm(dim=1), torch.ones(B), atol=1e-5)
 
 
+@pytest.mark.parametrize("E", [128, 512, 1024])
+def test_linear_l2norm_same_bits_on_both_paths(device, E):
+    """Up to 32 rows take the split kernel + norm replay, more rows the one-block kernel: a row's embedding must
+    not depend on the batch it arrived in, to the last bit."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(6)
+    a = torch.randn((40, 512), generator=g).half().to(device)
+    w = (torch.randn((E, 512), generator=g) / 22.0).half().to(device)
+    bias = (torch.randn(E, generator=g) * 0.1).to(device)
+    outs = []
+    for B in (40, 7):
+        out = torch.full((B, E), float("nan"), dtype=torch.float32, device=device)
+        _lib.check(lib.mfn_op_linear_l2norm(DT["f16"][1], a.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), B, 512,
+                                            E, stream(device)), "linear")
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0][:7], outs[1])
+
+
 @pytest.mark.parametrize("B,E", [(1, 512), (7, 512), (130, 128), (3, 100)])
 def test_tta_combine_and_l2norm(device, B, E):
     from face_recognition_amd.face_model import l2_norm, tta_combine
