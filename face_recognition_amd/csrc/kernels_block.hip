@@ -70,7 +70,6 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 //              at p == 4 after the PReLU: slope(q+1), then for q odd the project loop
 //              { WAIT fragment n; two MFMAs; issue fragment n + 4 }.
 // dw_outstanding() replays that order and returns the number of reads issued after the awaited one.
-constexpr int BLOCK_FEW_IMAGES = 8;   // batches up to this size run the short-band configurations
 constexpr int DW_STEPS = 20, DW_PD = 2, DW_RING = DW_PD + 1;   // reads run DW_PD steps ahead (3 measured no faster)
 constexpr int dw_outstanding(int nt16, int kind, int st, int n) {   // kind 0: taps(st); kind 1: fragment n in step st
     int issued = 7;
@@ -651,13 +650,26 @@ static int launch_block_cfg(const BlockParams& p, const void* x, void* out, int 
     return FRA_OK;
 }
 
+// compute units of the current device (asked once per device)
+static int compute_units() {
+    static std::atomic<int> cus_of[64];
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev < 64 && (cus = cus_of[dev].load(std::memory_order_relaxed)) > 0) return cus;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (dev < 64) cus_of[dev].store(cus, std::memory_order_relaxed);
+    return cus;
+}
+
 // Two band heights per shape.  The tall one has the least halo work and is what a full batch runs; with only a
 // few images it would leave most of the chip idle (conv_4 as whole-image bands: ONE workgroup per image), so
-// small batches run short bands: more redundant expand rows, but 7 to 14 workgroups per image side by side.
+// a batch whose SHORT bands still fit the chip in one go (one workgroup per compute unit) runs those: more
+// redundant expand rows, but 7 to 14 workgroups per image side by side.
 template <typename T>
 static int launch_block_t(const BlockParams& p, const void* x, void* out, int B, hipStream_t s) {
     const int key = p.cin * 1000000 + p.cexp * 1000 + p.h * 10 + p.stride;
-    const bool few = B <= BLOCK_FEW_IMAGES;
+    const int short_bands = (p.h / p.stride) >= 28 ? 14 : 7;   // of the short-band configurations below
+    const bool few = (int64_t)B * short_bands <= compute_units();
     switch (key) {
         case 64 * 1000000 + 128 * 1000 + 56 * 10 + 2:   // conv_23
             return few ? launch_block_cfg<T, 64, 128, 64, 56, 2, 2, false, 8, 2, 1, true>(p, x, out, B, s)

@@ -129,9 +129,10 @@ def _w3_image(w3pos, cout):
 def test_fused_block(device, dt, cin, cexp, cout, H, stride, res, B, many):
     """Fused expand/depthwise/project block against the three torch convs on 16-bit-rounded operands;
     the intermediate tensors are rounded to the storage type where the kernel rounds them.  The library runs
-    batches of up to 8 images with short bands and larger ones with tall bands: both are covered."""
+    a batch whose short bands fit the chip in one go (up to 18 or 36 images) with those and larger ones with
+    tall bands: both are covered."""
     if many:
-        B += 8
+        B = 40
     tdt, code, rel = DT[dt]
     lib = _lib.load()
     g = torch.Generator().manual_seed(11)
