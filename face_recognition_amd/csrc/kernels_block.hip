@@ -505,9 +505,22 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     // requested while the current image's last slice and epilogue still run.
     for (int img = blockIdx.y; img < B; img += gridDim.y) {
         const bool has_next = img + (int)gridDim.y < B;
-        // zero the activation image: borders and out-of-image rows are never written by the expand stage
-        // (the previous image's epilogue used this memory as staging)
-        for (int i = tid; i < ES_BYTES / 16; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // zero what the depthwise stage reads of the activation image but the expand stage never writes: the border
+        // slots 0 and W + 1 of every row and the rows outside the image (the previous image's epilogue used this
+        // memory as staging).  Every other slot a valid lane reads is written in full by each slice's expand.
+        {
+            constexpr int UB = 2 * 8, UR = PITCH * (SLOT / 16);   // 16-byte units: both border slots of a row; a whole row
+            for (int i = tid; i < RIN * UB; i += NT) {
+                const int ri = i / UB, u = i - ri * UB;
+                *reinterpret_cast<f32x4*>(lds + (ri * PITCH + (u >> 3) * (W + 1)) * SLOT + (u & 7) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            // band-uniform: LDS row 0 is image row row0 - ROFF, the last LDS row is image row row0 - ROFF + RIN - 1
+            if (row0 - ROFF < 0)
+                for (int i = tid; i < UR; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row0 - ROFF + RIN - 1 >= H)
+                for (int i = tid; i < UR; i += NT)
+                    reinterpret_cast<f32x4*>(lds + (RIN - 1) * PITCH * SLOT)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         // first image: this wave's pieces of slice 0, requested above.  Later images: they were waited for at the end of
         // the previous image's last slice, and waiting here would only drain that image's output stores.
         if (img == (int)blockIdx.y) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
