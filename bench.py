@@ -38,8 +38,8 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA, datasheet
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1024, help="crops per GPU per step")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--chunk", type=int, default=-1, help="batch slice size inside the library (-1 = tuned default)")
@@ -345,7 +345,7 @@ def main():
             extra[name] = {"faces_per_s": round(B * args.steps / (time.perf_counter() - t1), 1)}
         result["other_call_shapes"] = extra
     if rank == 0:
-        groups, total_ms = per_kernel_profile(net, x, 3, args.dtype)
+        groups, total_ms = per_kernel_profile(net, x, 10, args.dtype)
         dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
         gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
         traffic = None   # HBM bytes per launch from rocprofv3 PMC passes (profiles/, separate runs of this command)
