@@ -91,25 +91,55 @@ def per_kernel_profile(net, x, reps, dt):
     return groups, float(ms.sum())
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(seconds):
-    """The CPU oracle on this host: batches of 32 crops, fp32, un-fused graph, for about `seconds`."""
-    from oracle import mobilefacenet_ref
+    """The CPU oracle on this host: batches of 32 crops, fp32, un-fused graph, for about `seconds` on up to 16
+    threads, then a short single-thread sample, then the reference's broadcast match (cam_demo.py:97-99) of
+    32 embeddings against 1000 rows."""
+    from oracle import matching_ref, mobilefacenet_ref
     threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(1, 512).items()}
     x = torch.from_numpy(synthetic.make_crops(32, 0))
-    for _ in range(2):
-        mobilefacenet_ref.forward(sd, x)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        mobilefacenet_ref.forward(sd, x)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or n >= 400:
-            break
+
+    def timed(nthreads, budget, cap):
+        torch.set_num_threads(nthreads)
+        for _ in range(2):
+            y = mobilefacenet_ref.forward(sd, x)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            y = mobilefacenet_ref.forward(sd, x)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget or n >= cap:
+                return n, el, y
+
+    n, el, y = timed(threads, seconds, 400)
+    n1, el1, _ = timed(1, min(6.0, seconds / 2), 50)
+    torch.set_num_threads(threads)
+    bank = torch.from_numpy(synthetic.unit_rows(1000, 512, seed=2))
+    for _ in range(3):
+        matching_ref.match_broadcast(y, bank, 60)
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        matching_ref.match_broadcast(y, bank, 60)
+        ts.append(time.perf_counter() - t0)
     return {"value": round(32 * n / el, 1), "unit": "faces/s", "cores": threads, "kind": "port",
             "sample": f"{n} batches of 32 crops (fp32 un-fused PyTorch graph of the oracle) in {el:.1f} s; "
-                      f"host has {os.cpu_count()} logical CPUs"}
+                      f"host has {os.cpu_count()} logical CPUs",
+            "one_thread_faces_per_s": round(32 * n1 / el1, 1),
+            "match_32x1000_queries_per_s": round(32 / float(np.median(ts)), 1),
+            "cpu_model": _cpu_model(), "torch": torch.__version__}
 
 
 CHUNK_ROWS = 1 << 18  # the synthetic gallery is defined in global chunks of 262,144 rows
@@ -188,9 +218,11 @@ def latency(net, dev):
     bank = torch.from_numpy(synthetic.unit_rows(1000, 512, seed=2)).to(dev)
     rec = GraphedRecognizer(net, bank, tta=False, threshold=60)
     rec_tta = GraphedRecognizer(net, bank, tta=True, threshold=60)
+    bank5 = torch.from_numpy(synthetic.unit_rows(5, 512, seed=4)).to(dev)      # the size of the facebank the reference ships
+    rec5 = GraphedRecognizer(net, bank5, tta=False, threshold=60)
 
-    def timeit(fn, x, reps=300):
-        for _ in range(30):
+    def timeit(fn, x, reps=1000, warm=100):
+        for _ in range(warm):
             fn(x)
         torch.cuda.synchronize()
         ts = []
@@ -205,9 +237,10 @@ def latency(net, dev):
     out = {}
     for B in (1, 2, 4, 8):
         x = torch.rand((B, 3, 112, 112), device=dev) * 2 - 1
-        out[f"b{B}"] = {"eager_forward": timeit(net, x, 100),
-                        "eager_forward_match": timeit(lambda t: match_facebank(net(t), bank, 60), x, 100),
+        out[f"b{B}"] = {"eager_forward": timeit(net, x, 300, 30),
+                        "eager_forward_match": timeit(lambda t: match_facebank(net(t), bank, 60), x, 300, 30),
                         "graph_forward_match": timeit(rec, x),
+                        "graph_forward_match_bank5": timeit(rec5, x),
                         "graph_tta_forward_match": timeit(rec_tta, x)}
     return out
 
