@@ -77,6 +77,8 @@ def per_kernel_profile(net, x, reps, dt):
     """Average per-op milliseconds (HIP events on the launch stream, inside the library), grouped by kernel."""
     acc = None
     for _ in range(reps):
+        for _ in range(4):      # the timed call synchronises; un-timed forwards in front of it keep the clocks where the timed region had them
+            net(x)
         _, ms, table = net.forward_timed(x)
         acc = ms if acc is None else acc + ms
     ms = acc / reps
