@@ -197,7 +197,7 @@ def run_search(args, rank, world, dev, dist_mod):
     torch.cuda.synchronize()
     if world > 1:
         dist_mod.barrier()
-    el = torch.tensor([time.perf_counter() - t0], device=dev)
+    el = torch.tensor([time.perf_counter() - t0], device=dev if world == 1 or dist_mod.get_backend() == "nccl" else "cpu")
     if world > 1:
         dist_mod.all_reduce(el, op=dist_mod.ReduceOp.MAX)
     el = float(el) / args.search_steps
@@ -206,7 +206,7 @@ def run_search(args, rank, world, dev, dist_mod):
     return {"metric": "1:N top-5 queries/sec", "value": round(Q / el, 1), "unit": "queries/s", "queries": Q,
             "gallery_rows": total, "rows_per_gpu": e - b, "k": 5, "gallery_dtype": "f16", "ms_per_batch": round(el * 1e3, 3),
             "scaling": "strong", "planted_top1_hit_rate": round(hit, 5), "gallery_build_s": round(build_s, 2),
-            "merge": "RCCL all_gather + fb_merge_topk" if world > 1 else "none (1 shard)",
+            "merge": (("RCCL" if dist_mod.get_backend() == "nccl" else dist_mod.get_backend()) + " all_gather + fb_merge_topk") if world > 1 else "none (1 shard)",
             "roofline": {"bound": "mfma", "achieved": round(flops / el / 1e12, 2), "peak": MFMA_PEAK_TFLOPS * world,
                          "unit": "TFLOP/s", "frac": round(flops / el / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
                          "traffic": None}}
@@ -295,6 +295,9 @@ def verification_12k(net, dev, pairs=12000, batch=256):
 
 def main():
     args = parse()
+    if os.environ.get("FRA_BENCH_WATCHDOG"):     # dump every thread's stack and exit if the run takes longer than this many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["FRA_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -304,13 +307,21 @@ def main():
         raise SystemExit("launch multi-GPU runs with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
+    # rehearsal on a one-GPU box: FRA_BENCH_ONE_GPU=1 puts every rank on cuda:0, FRA_BENCH_BACKEND=gloo replaces RCCL
+    # (which refuses two ranks on one device); the control flow and the collectives' shapes are the real ones
+    if os.environ.get("FRA_BENCH_ONE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("FRA_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     sd = synthetic.make_state_dict(1, 512)
     net = MobileFaceNet(512, act_dtype=args.dtype)
@@ -342,7 +353,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if world == 1 or dist.get_backend() == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     el = float(el)

@@ -47,8 +47,14 @@ def allgather_topk(local_dist: torch.Tensor, local_idx: torch.Tensor, group=None
     packed = torch.empty((q, 2 * k), dtype=torch.int32, device=local_dist.device)
     packed[:, :k] = local_dist.contiguous().view(torch.int32)
     packed[:, k:] = local_idx.to(torch.int32)
-    gathered = torch.empty((world, q, 2 * k), dtype=torch.int32, device=local_dist.device)
-    dist.all_gather_into_tensor(gathered.view(world * q, 2 * k), packed, group=group)
+    if packed.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo moves device tensors through the host itself, and its device path hangs on this stack: stage them here
+        host = torch.empty((world, q, 2 * k), dtype=torch.int32)
+        dist.all_gather_into_tensor(host.view(world * q, 2 * k), packed.cpu(), group=group)
+        gathered = host.to(packed.device)
+    else:
+        gathered = torch.empty((world, q, 2 * k), dtype=torch.int32, device=local_dist.device)
+        dist.all_gather_into_tensor(gathered.view(world * q, 2 * k), packed, group=group)
     d = gathered[:, :, :k].contiguous().view(torch.float32)
     i = gathered[:, :, k:].contiguous()
     return d, i
@@ -110,6 +116,11 @@ def gather_embeddings(local_emb: torch.Tensor, total: int, group=None) -> torch.
     maxn = max(e - b for b, e in sizes)
     pad = torch.zeros((maxn, local_emb.shape[1]), dtype=local_emb.dtype, device=local_emb.device)
     pad[: local_emb.shape[0]] = local_emb
-    out = torch.empty((world * maxn, local_emb.shape[1]), dtype=local_emb.dtype, device=local_emb.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    if pad.is_cuda and dist.get_backend(group) == "gloo":     # as in allgather_topk
+        host = torch.empty((world * maxn, local_emb.shape[1]), dtype=local_emb.dtype)
+        dist.all_gather_into_tensor(host, pad.cpu(), group=group)
+        out = host.to(local_emb.device)
+    else:
+        out = torch.empty((world * maxn, local_emb.shape[1]), dtype=local_emb.dtype, device=local_emb.device)
+        dist.all_gather_into_tensor(out, pad, group=group)
     return torch.cat([out[r * maxn: r * maxn + (e - b)] for r, (b, e) in enumerate(sizes)], 0)
