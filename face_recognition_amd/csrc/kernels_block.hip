@@ -71,21 +71,21 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 //              { WAIT fragment n; two MFMAs; issue fragment n + 4 }.
 // dw_outstanding() replays that order and returns the number of reads issued after the awaited one.
 constexpr int DW_STEPS = 20, DW_PD = 2, DW_RING = DW_PD + 1;   // reads run DW_PD steps ahead (3 measured no faster)
-constexpr int dw_outstanding(int nt16, int kind, int st, int n) {   // kind 0: taps(st); kind 1: fragment n in step st
+constexpr int dw_outstanding(int nt16, int nq, int kind, int st, int n) {   // kind 0: taps(st); kind 1: fragment n in step st
     int issued = 7;
     int taps_idx[DW_STEPS] = {};
     int a3_idx[64] = {};
     for (int i = 0; i < DW_PD; ++i) { issued += 2; taps_idx[i] = issued - 1; }
-    for (int ST = 0; ST < DW_STEPS; ++ST) {
+    for (int ST = 0; ST < 5 * nq; ++ST) {
         const int q = ST / 5, p = ST % 5;
-        if (ST + DW_PD < DW_STEPS) { issued += 2; taps_idx[ST + DW_PD] = issued - 1; }
+        if (ST + DW_PD < 5 * nq) { issued += 2; taps_idx[ST + DW_PD] = issued - 1; }
         if ((q & 1) && p == 2)
             for (int i = 0; i < cmin(4, nt16); ++i) { issued += 1; a3_idx[i] = issued - 1; }
         if (kind == 0 && st == ST) return cmin(issued - 1 - taps_idx[ST], 15);
-        if (q + 1 < 4) issued += 1;                       // w16 of the next chunk
-        if (p == 0 && q + 1 < 4) issued += 1;             // bias of the next chunk
+        if (q + 1 < nq) issued += 1;                      // w16 of the next chunk
+        if (p == 0 && q + 1 < nq) issued += 1;            // bias of the next chunk
         if (p == 4) {
-            if (q + 1 < 4) issued += 1;                   // slope of the next chunk
+            if (q + 1 < nq) issued += 1;                  // slope of the next chunk
             if (q & 1)
                 for (int i = 0; i < nt16; ++i) {
                     if (kind == 1 && st == ST && n == i) return cmin(issued - 1 - a3_idx[i], 15);
@@ -112,6 +112,7 @@ typedef __attribute__((address_space(3))) void* LPTR;        // its (wave-unifor
 __device__ __forceinline__ int cmin_rt(int a, int b) { return a < b ? a : b; }
 
 
+template <int CIN, int CEXP, int COUT, int H, int S, int TR, int MODE, int KSPLIT> constexpr int block_lds_bytes();
 template <int H, int S> constexpr int block_pitch() {
     return S == 2 ? (H >= 28 ? ((H + 2) | 1) : H + 2) : (H >= 14 ? (H + 2 + 15) / 16 * 16 : H + 2);
 }
@@ -172,7 +173,8 @@ template <typename T, int KS1, int CEXP, int PW1> struct ExpStage {
 // bias (the MFMA's C operand), PReLU and rounding IS its half of the project MFMA's B operand for the
 // chunk pair (k = 8 g + j: j < 4 from the even chunk, j >= 4 from the odd one; the project weights are
 // stored in that order when their slice is staged).
-template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB> struct DwStage {
+// NQ: chunks of the slice this wave handles (4, or 2 = one chunk pair when two waves share a tile)
+template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ> struct DwStage {
     typedef typename vec8<T>::type V8;
     V8 er[DW_RING][2];             // ring: image unit of a tap pair, per subtile
     V8 a3[4];                      // ring: project fragments
@@ -217,7 +219,7 @@ template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB> struct DwS
     }
     template <int ST, int PAIR, int N = 0> __device__ __forceinline__ void project(f32x4 (&pacc)[2][NT16]) {
         if constexpr (N < NT16) {
-            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a3[N & 3]) : "n"(dw_outstanding(NT16, 1, ST, N)));
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a3[N & 3]) : "n"(dw_outstanding(NT16, NQ, 1, ST, N)));
             pacc[0][N] = mfma16(a3[N & 3], bf[0], pacc[0][N]);
             pacc[1][N] = mfma16(a3[N & 3], bf[1], pacc[1][N]);
             if constexpr (N + 4 < NT16) {
@@ -229,31 +231,31 @@ template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB> struct DwS
         }
     }
     template <int ST = 0> __device__ __forceinline__ void run(f32x4 (&pacc)[2][NT16]) {
-        if constexpr (ST < DW_STEPS) {
+        if constexpr (ST < 5 * NQ) {
             constexpr int q = ST / 5, p = ST % 5, slot = ST % DW_RING;
-            if constexpr (ST + DW_PD < DW_STEPS) issue_taps<ST + DW_PD>();
+            if constexpr (ST + DW_PD < 5 * NQ) issue_taps<ST + DW_PD>();
             if constexpr ((q & 1) && p == 2) issue_a3_first<(q >> 1)>();
             // everything issued before taps(ST) has landed with them: w16[p], bias (p == 0), slope (p == 4)
             if constexpr (p == 0)
                 asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(er[slot][0]), "+v"(er[slot][1]), "+v"(w16[p]), "+v"(bias)
-                             : "n"(dw_outstanding(NT16, 0, ST, 0)));
+                             : "n"(dw_outstanding(NT16, NQ, 0, ST, 0)));
             else if constexpr (p == 4)
                 asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(er[slot][0]), "+v"(er[slot][1]), "+v"(w16[p]), "+v"(slope)
-                             : "n"(dw_outstanding(NT16, 0, ST, 0)));
+                             : "n"(dw_outstanding(NT16, NQ, 0, ST, 0)));
             else
                 asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(er[slot][0]), "+v"(er[slot][1]), "+v"(w16[p])
-                             : "n"(dw_outstanding(NT16, 0, ST, 0)));
+                             : "n"(dw_outstanding(NT16, NQ, 0, ST, 0)));
             const uint32_t wd = w16[p] | (w16[p] << 16);
             const u32x4 du = {wd & msk[0], wd & msk[1], wd & msk[2], wd & msk[3]};
             const V8 dg = __builtin_bit_cast(V8, du);
-            if constexpr (q + 1 < 4) {
+            if constexpr (q + 1 < NQ) {
                 __builtin_amdgcn_sched_barrier(0);
                 issue_w16<q + 1, p>();
             }
             if constexpr (p == 0) {
                 acc[0] = mfma16(dg, er[slot][0], bias);
                 acc[1] = mfma16(dg, er[slot][1], bias);
-                if constexpr (q + 1 < 4) {
+                if constexpr (q + 1 < NQ) {
                     __builtin_amdgcn_sched_barrier(0);
                     issue_bias<q + 1>();
                 }
@@ -269,7 +271,7 @@ template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB> struct DwS
                         const float d = acc[s][i];
                         bf[s][4 * (q & 1) + i] = (T)fmaf(neg_part(d), slope[i], d);   // PReLU: slope holds slope - 1
                     }
-                if constexpr (q + 1 < 4) {
+                if constexpr (q + 1 < NQ) {
                     __builtin_amdgcn_sched_barrier(0);
                     issue_slope<q + 1>();
                 }
@@ -284,7 +286,7 @@ template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB> struct DwS
     }
 };
 
-template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW, int MODE>
+template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW, int MODE, int KSPLIT>
 __global__ __launch_bounds__(NW * 64, MINW)
 void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float* __restrict__ b1p,
                   const float* __restrict__ s1p, const T* __restrict__ W2p, const float* __restrict__ b2p,
@@ -315,7 +317,8 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     constexpr int ES_BYTES = RIN * PITCH * SLOT;
     constexpr int W1_BYTES = 64 * PW1, W3_BYTES = 2 * COUT * PW3, WB_BYTES = W1_BYTES + W3_BYTES;
     constexpr int P32 = COUT * 4 + 16;                     // epilogue staging: f32 pixel rows, padded
-    constexpr int EPI_BYTES = POUT * P32;                  // overlays the image and weight buffer 1
+    constexpr int EPI1 = POUT * P32;                       // one set of staging rows
+    constexpr int EPI_BYTES = KSPLIT * EPI1;               // overlays the image and weight buffer 1
     constexpr int PW2 = CEXP * 2 + 32;                     // 3x3 weight rows, padded so that the two taps of a pair sit on different banks
     // LDS map: image | weight buffer 1 (odd slices) | per-channel parameters | 3x3 weights | weight buffer 0 (even
     // slices).  The epilogue's staging rows overlay the image and buffer 1 only: buffer 0 can receive the next
@@ -333,9 +336,15 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     static_assert(MODE == 1, "two copies of the weight slices");
     static_assert(CEXP % 64 == 0 && CIN % 16 == 0 && COUT % 32 == 0 && Ho % TR == 0, "shape");
     constexpr int MTIW = (MTI + NW - 1) / NW;              // input tiles per wave (stride-2 bands have more input than output)
-    static_assert(MTO <= NW, "one output tile per wave");
+    // Depthwise / project side: wave -> (output tile wt, chunk pair kp).  KSPLIT = 2 (shapes with at most four
+    // output tiles per band): two waves share a tile, each takes one 32-channel chunk pair of every slice and
+    // accumulates its own partial project sums; the epilogue adds the two.  MTOW: tiles rounded up to a power of two.
+    constexpr int MTOW = MTO > 4 ? 8 : (MTO > 2 ? 4 : (MTO > 1 ? 2 : 1));
+    static_assert(KSPLIT == 1 || KSPLIT == 2, "chunk pairs of a slice");
+    static_assert(KSPLIT * MTOW <= NW || (KSPLIT == 1 && MTO <= NW), "one (output tile, chunk pair) per wave");
     static_assert(!RESID || (S == 1 && CIN == COUT), "shortcut needs matching shapes");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(LDS_BYTES == block_lds_bytes<CIN, CEXP, COUT, H, S, TR, MODE, KSPLIT>(), "the launcher's LDS size is this map's");
     static_assert(NT % (COUT / 4) == 0, "epilogue: a thread keeps one channel group");
     static_assert(EPI_BYTES <= OFF_PAR, "the epilogue staging must not reach the per-channel parameters");
     static_assert(NCH % 2 == 0, "slice 0 of the next image goes to the buffer the last slice does not use");
@@ -414,6 +423,8 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 
     // ---- output pixels of this lane on the depthwise / project side: pixel m of each 16-pixel subtile ----------
     const int m16 = lane & 15, g4 = lane >> 4;
+    const int wt = KSPLIT == 1 ? wave : (wave & (MTOW - 1)), kp = KSPLIT == 1 ? 0 : wave / MTOW;   // wave-uniform
+    const bool dw_active = wt < MTO && kp < KSPLIT;
     // Subtile 1 holds the pixels 16 lanes further on in the tile: 16 columns further (one tile row of 32), the next
     // row (16) or two rows further (8), always a fixed number of bytes after subtile 0's.  Lanes without an
     // output pixel still read -- their own (unused) column and row, so that the 16 lanes of a read group keep
@@ -428,7 +439,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     int po0;              // this lane's pixel of subtile 0 inside the band; subtile 1 is PO1 further
     constexpr int PO1 = POW == 32 ? 16 : (16 / POW) * Wo;
     {
-        const int oy = wave * RPT + m16 / POW, ox = m16 % POW;
+        const int oy = wt * RPT + m16 / POW, ox = m16 % POW;
         po0 = oy * Wo + ox;
         out_ok[0] = (ox < Wo) && (oy < TR);
         out_ok[1] = POW == 32 ? (ox + 16 < Wo) && (oy < TR) : (ox < Wo) && (oy + 16 / POW < TR);
@@ -483,19 +494,20 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 
     // ================= depthwise 3x3 of slice c from the LDS image -> project MFMA =================================
     auto dwproject = [&](int c, int wb, int eb) {
-        if (wave >= MTO) return;                           // wave-uniform
-        DwStage<T, CEXP, NT16, PW3, ST1, PITCH * SLOT> dw;
-        dw.tb[0] = tb[0] + eb * ES_BYTES;
-        dw.tb[1] = tb[1] + eb * ES_BYTES;
+        if (!dw_active) return;                            // wave-uniform
+        DwStage<T, CEXP, NT16, PW3, ST1, PITCH * SLOT, 4 / KSPLIT> dw;
+        // a wave that takes chunk pair kp of the slice starts 2 kp chunks further in every per-chunk array
+        dw.tb[0] = tb[0] + eb * ES_BYTES + 64 * kp;
+        dw.tb[1] = tb[1] + eb * ES_BYTES + 64 * kp;
         // diagonal fragment: element j of register pair j >> 1 is non-zero where channel 8 (g >> 1) + j is this lane's row
         // (rebuilt per slice from the lane index: four registers that need not live through the expand stage)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             dw.msk[i] = ((m16 >> 3) == (g4 >> 1) && ((m16 & 7) >> 1) == i) ? ((m16 & 1) ? 0xFFFF0000u : 0x0000FFFFu) : 0u;
-        dw.w2l[0] = OFF_W2 + (g4 & 1) * PW2 + (64 * c + m16) * 2;
-        dw.w2l[1] = OFF_W2 + (5 + 4 * (g4 & 1)) * PW2 + (64 * c + m16) * 2;
-        dw.pb = OFF_B2 + 256 * c + 16 * g4;
-        dw.w3l = (wb ? OFF_WB1 : OFF_WB0) + W1_BYTES + (16 * (g4 & 1) + m16) * PW3 + 16 * (g4 >> 1);
+        dw.w2l[0] = OFF_W2 + (g4 & 1) * PW2 + (64 * c + 32 * kp + m16) * 2;
+        dw.w2l[1] = OFF_W2 + (5 + 4 * (g4 & 1)) * PW2 + (64 * c + 32 * kp + m16) * 2;
+        dw.pb = OFF_B2 + 256 * c + 128 * kp + 16 * g4;
+        dw.w3l = (wb ? OFF_WB1 : OFF_WB0) + W1_BYTES + (16 * (g4 & 1) + m16) * PW3 + 16 * (g4 >> 1) + 32 * kp;
         dw.preamble();
         dw.run(pacc);
     };
@@ -571,11 +583,11 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
             }
         };
         fetch_shortcut(std::integral_constant<int, 0>{});
-        if (wave < MTO) {
+        if (dw_active) {
     #pragma unroll
             for (int st = 0; st < 2; ++st)
                 if (out_ok[st]) {
-                    char* dst = lds + (po0 + st * PO1) * P32 + 16 * g4;
+                    char* dst = lds + kp * EPI1 + (po0 + st * PO1) * P32 + 16 * g4;
     #pragma unroll
                     for (int n = 0; n < NT16; ++n) *reinterpret_cast<f32x4*>(dst + 64 * n) = pacc[st][n];
                 }
@@ -593,6 +605,11 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
                     const int it = k * EPI_CH + j;
                     if (it < EPI_IT && p0 + it * PSTEP < POUT) {
                         f32x4 v = *reinterpret_cast<const f32x4*>(ls + it * PSTEP * P32);
+                        if constexpr (KSPLIT == 2) {   // the other chunk pairs' partial sums
+                            const f32x4 v2 = *reinterpret_cast<const f32x4*>(ls + EPI1 + it * PSTEP * P32);
+    #pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] += v2[i];
+                        }
                         if (RESID) {
     #pragma unroll
                             for (int i = 0; i < 4; ++i) v[i] += (float)rr[k & 1][j][i];
@@ -610,13 +627,13 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int CEXP, int COUT, int H, int S, int TR, int MODE>
+template <int CIN, int CEXP, int COUT, int H, int S, int TR, int MODE, int KSPLIT>
 constexpr int block_lds_bytes() {
     // mirrors the LDS map of block_kernel
     constexpr int RIN = (S == 1) ? TR + 2 : 2 * TR + 1;
     constexpr int es = RIN * block_pitch<H, S>() * 144;
     constexpr int wb = 64 * (CIN * 2 + 16) + COUT * 160;
-    constexpr int epi = TR * (H / S) * (COUT * 4 + 16);
+    constexpr int epi = KSPLIT * TR * (H / S) * (COUT * 4 + 16);
     constexpr int off_par = (cmax(es + wb, epi) + 15) / 16 * 16;
     return off_par + 4 * CEXP * 4 + 13 * (CEXP * 2 + 32) + wb;
 }
@@ -631,7 +648,7 @@ static int resident_workgroups(const void* kernel, int threads, int lds_bytes) {
     return cus * per_cu;
 }
 
-template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW, int MODE, bool PERSIST>
+template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW, int MODE, bool PERSIST, int KSPLIT>
 static int launch_block_cfg(const BlockParams& p, const void* x, void* out, int B, hipStream_t s) {
     FRA_REQUIRE(p.cout == COUT, FRA_ERR_ARG, "block: cout %d, fused kernel has %d", p.cout, COUT);
     // PERSIST: one workgroup per band and resident slot, each walking over the images blockIdx.y,
@@ -639,8 +656,8 @@ static int launch_block_cfg(const BlockParams& p, const void* x, void* out, int 
     // ceil(B / slots) images per workgroup).  Otherwise one workgroup per band and image, which balances
     // better when the bands do not divide the resident slots evenly.
     const int bands = (H / S) / TR;
-    constexpr int lds = block_lds_bytes<CIN, CEXP, COUT, H, S, TR, MODE>();
-    auto kern = block_kernel<T, CIN, CEXP, COUT, H, S, TR, RESID, NW, MINW, MODE>;
+    constexpr int lds = block_lds_bytes<CIN, CEXP, COUT, H, S, TR, MODE, KSPLIT>();
+    auto kern = block_kernel<T, CIN, CEXP, COUT, H, S, TR, RESID, NW, MINW, MODE, KSPLIT>;
     static std::atomic<uint64_t> lds_set;      // per instantiation: devices whose LDS limit is raised
     static std::atomic<int> slots_of[64];      // resident workgroups per band, per device (0 = not asked yet)
     int dev = 0;
@@ -685,23 +702,23 @@ static int launch_block_t(const BlockParams& p, const void* x, void* out, int B,
     const bool few = (int64_t)B * short_bands <= compute_units();
     switch (key) {
         case 64 * 1000000 + 128 * 1000 + 56 * 10 + 2:   // conv_23
-            return few ? launch_block_cfg<T, 64, 128, 64, 56, 2, 2, false, 8, 2, 1, true>(p, x, out, B, s)
-                       : launch_block_cfg<T, 64, 128, 64, 56, 2, 4, false, 8, 2, 1, true>(p, x, out, B, s);
+            return few ? launch_block_cfg<T, 64, 128, 64, 56, 2, 2, false, 8, 2, 1, true, 2>(p, x, out, B, s)
+                       : launch_block_cfg<T, 64, 128, 64, 56, 2, 4, false, 8, 2, 1, true, 2>(p, x, out, B, s);
         case 64 * 1000000 + 128 * 1000 + 28 * 10 + 1:   // conv_3.*
-            return few ? launch_block_cfg<T, 64, 128, 64, 28, 1, 2, true, 8, 2, 1, true>(p, x, out, B, s)
-                       : launch_block_cfg<T, 64, 128, 64, 28, 1, 7, true, 8, 2, 1, true>(p, x, out, B, s);
+            return few ? launch_block_cfg<T, 64, 128, 64, 28, 1, 2, true, 8, 2, 1, true, 1>(p, x, out, B, s)
+                       : launch_block_cfg<T, 64, 128, 64, 28, 1, 7, true, 8, 2, 1, true, 1>(p, x, out, B, s);
         case 64 * 1000000 + 256 * 1000 + 28 * 10 + 2:   // conv_34
-            return few ? launch_block_cfg<T, 64, 256, 128, 28, 2, 2, false, 8, 2, 1, true>(p, x, out, B, s)
-                       : launch_block_cfg<T, 64, 256, 128, 28, 2, 7, false, 8, 2, 1, true>(p, x, out, B, s);
+            return few ? launch_block_cfg<T, 64, 256, 128, 28, 2, 2, false, 8, 2, 1, true, 2>(p, x, out, B, s)
+                       : launch_block_cfg<T, 64, 256, 128, 28, 2, 7, false, 8, 2, 1, true, 2>(p, x, out, B, s);
         case 128 * 1000000 + 256 * 1000 + 14 * 10 + 1:  // conv_4.*
-            return few ? launch_block_cfg<T, 128, 256, 128, 14, 1, 2, true, 8, 2, 1, true>(p, x, out, B, s)
-                       : launch_block_cfg<T, 128, 256, 128, 14, 1, 14, true, 8, 2, 1, true>(p, x, out, B, s);
+            return few ? launch_block_cfg<T, 128, 256, 128, 14, 1, 2, true, 8, 2, 1, true, 1>(p, x, out, B, s)
+                       : launch_block_cfg<T, 128, 256, 128, 14, 1, 14, true, 8, 2, 1, true, 1>(p, x, out, B, s);
         case 128 * 1000000 + 512 * 1000 + 14 * 10 + 2:  // conv_45
-            return few ? launch_block_cfg<T, 128, 512, 128, 14, 2, 1, false, 8, 2, 1, true>(p, x, out, B, s)
-                       : launch_block_cfg<T, 128, 512, 128, 14, 2, 7, false, 8, 2, 1, true>(p, x, out, B, s);
+            return few ? launch_block_cfg<T, 128, 512, 128, 14, 2, 1, false, 8, 2, 1, true, 2>(p, x, out, B, s)
+                       : launch_block_cfg<T, 128, 512, 128, 14, 2, 7, false, 8, 2, 1, true, 2>(p, x, out, B, s);
         case 128 * 1000000 + 256 * 1000 + 7 * 10 + 1:   // conv_5.*
-            return few ? launch_block_cfg<T, 128, 256, 128, 7, 1, 1, true, 8, 2, 1, true>(p, x, out, B, s)
-                       : launch_block_cfg<T, 128, 256, 128, 7, 1, 7, true, 8, 2, 1, true>(p, x, out, B, s);
+            return few ? launch_block_cfg<T, 128, 256, 128, 7, 1, 1, true, 8, 2, 1, true, 2>(p, x, out, B, s)
+                       : launch_block_cfg<T, 128, 256, 128, 7, 1, 7, true, 8, 2, 1, true, 2>(p, x, out, B, s);
         default: break;
     }
     FRA_REQUIRE(false, FRA_ERR_ARG, "block: no fused kernel for cin=%d cexp=%d h=%d stride=%d", p.cin, p.cexp, p.h,

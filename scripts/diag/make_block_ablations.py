@@ -41,9 +41,7 @@ variant("noprelu", [("                        bf[s][4 * (q & 1) + i] = (T)fmaf(n
                      "                        bf[s][4 * (q & 1) + i] = (T)d;")])
 variant("nodwstage", [("            dwproject(c, c & 1, 0);\n", "")])
 variant("noexpand", [("            expand(c, c & 1, 0);\n", "")])
-variant("nozero", [(
-    "        for (int i = tid; i < ES_BYTES / 16; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};\n",
-    "        if (img == (int)blockIdx.y) for (int i = tid; i < ES_BYTES / 16; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};\n")])
+variant("nozero", [("        {\n            constexpr int UB = 2 * 8,", "        if (img == (int)blockIdx.y) {\n            constexpr int UB = 2 * 8,")])
 variant("noshortcut", [
     ("            if constexpr (RESID && k < EPI_NCH) {", "            if constexpr (false && k < EPI_NCH) {"),
     ("                        if (RESID) {\n    #pragma unroll\n                            for (int i = 0; i < 4; ++i) v[i] += (float)rr[k & 1][j][i];\n                        }", ""),
@@ -52,7 +50,7 @@ variant("lessstagew", [(  # only buffer 1 (which the epilogue overwrites) is sta
     "            if (c + 1 < NCH) stage_w(c + 1, (c + 1) & 1);  // that buffer was last read before the previous barrier\n            else if (has_next) stage_w(0, 0);\n",
     "            if (c == 0) stage_w(1, 1);\n")])
 variant("noepilogue", [
-    ("        fetch_shortcut(std::integral_constant<int, 0>{});\n        if (wave < MTO) {", KEEP + "        if (false) {"),
+    ("        fetch_shortcut(std::integral_constant<int, 0>{});\n        if (dw_active) {", KEEP + "        if (false) {"),
     ("        __syncthreads();\n        {\n            const f32x4 bias = *reinterpret_cast<const f32x4*>(b3 + 4 * g);",
      "        if (B < 0) {\n            const f32x4 bias = *reinterpret_cast<const f32x4*>(b3 + 4 * g);"),
 ])
