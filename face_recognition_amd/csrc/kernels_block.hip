@@ -336,6 +336,10 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     static_assert(MODE == 1, "two copies of the weight slices");
     static_assert(CEXP % 64 == 0 && CIN % 16 == 0 && COUT % 32 == 0 && Ho % TR == 0, "shape");
     constexpr int MTIW = (MTI + NW - 1) / NW;              // input tiles per wave (stride-2 bands have more input than output)
+    // Expand side: wave -> (input tile we, channel tile en of the slice).  With at most four input tiles (ESPLIT) two
+    // waves share a tile and expand one 32-channel tile of the slice each; otherwise a wave does both.
+    constexpr bool ESPLIT = MTI <= NW / 2;
+    constexpr int MTIP = MTI > 2 ? 4 : (MTI > 1 ? 2 : 1);   // (ESPLIT) input tiles rounded up to a power of two
     // Depthwise / project side: wave -> (output tile wt, chunk pair kp).  KSPLIT = 2 (shapes with at most four
     // output tiles per band): two waves share a tile, each takes one 32-channel chunk pair of every slice and
     // accumulates its own partial project sums; the epilogue adds the two.  MTOW: tiles rounded up to a power of two.
@@ -403,9 +407,10 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     V8 xf[MTIW][KS1];
     int in_lds[MTIW];     // LDS byte address of this lane's input pixel slot (+ 16 h), -1 = nothing to write
     int x_off[MTIW];      // element offset of this lane's input pixel inside an image (+ 8 h)
+    const int we = ESPLIT ? (wave & (MTIP - 1)) : wave, en = ESPLIT ? wave / MTIP : 0;   // wave-uniform
 #pragma unroll
     for (int t = 0; t < MTIW; ++t) {
-        const int p = 32 * (wave + NW * t) + r;
+        const int p = 32 * (we + NW * t) + r;
         const int iy = p / W, ix = p - iy * W;
         const int gy = row0 + iy;
         const bool ok = (p < PIN) && (gy >= 0) && (gy < H);
@@ -475,21 +480,25 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         }
     };
     auto expand = [&](int c, int wb, int eb) {
-        if (wave >= MTI) return;                           // wave-uniform; such a wave has no later tile either
+        if (we >= MTI || en >= 2) return;                  // wave-uniform; such a wave has no later tile either
         const int eoff = eb * ES_BYTES;
         Ex ex;   // lives only inside this call, so its registers are free for the other stage
         ex.w1l = (wb ? OFF_WB1 : OFF_WB0) + r * PW1 + 16 * h;
         ex.pl = OFF_B1 + 256 * c + 32 * h;
-        ex.template issue<0>();
-        expand_tile(ex, 0, std::true_type{}, 0, eoff);
+        if (!ESPLIT || en == 0) {
+            ex.template issue<0>();
+            expand_tile(ex, 0, std::true_type{}, 0, eoff);
 #pragma unroll
-        for (int t = 1; t < MTIW; ++t)
-            if (wave + NW * t < MTI) expand_tile(ex, t, std::false_type{}, 0, eoff);
-        ex.template issue<1>();
-        expand_tile(ex, 0, std::true_type{}, 1, eoff);
+            for (int t = 1; t < MTIW; ++t)
+                if (we + NW * t < MTI) expand_tile(ex, t, std::false_type{}, 0, eoff);
+        }
+        if (!ESPLIT || en == 1) {
+            ex.template issue<1>();
+            expand_tile(ex, 0, std::true_type{}, 1, eoff);
 #pragma unroll
-        for (int t = 1; t < MTIW; ++t)
-            if (wave + NW * t < MTI) expand_tile(ex, t, std::false_type{}, 1, eoff);
+            for (int t = 1; t < MTIW; ++t)
+                if (we + NW * t < MTI) expand_tile(ex, t, std::false_type{}, 1, eoff);
+        }
     };
 
     // ================= depthwise 3x3 of slice c from the LDS image -> project MFMA =================================
