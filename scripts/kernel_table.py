@@ -1,4 +1,4 @@
-"""Prints the kernel table of DESIGN.md section 4 from profiles/r01_bench.json, r01_kernel_stats.csv and r01_pmc_traffic.json."""
+"""Prints the per-kernel table (event and rocprofv3 durations, algorithmic and measured bytes, GB/s, TFLOP/s) from profiles/r01_bench.json, r01_kernel_stats.csv and r01_pmc_traffic.json."""
 import csv, json, os, re
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 r = json.load(open(os.path.join(root, "profiles/r01_bench.json")))

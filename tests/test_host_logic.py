@@ -13,7 +13,7 @@ from oracle import evaluation_ref
 from test_oracle_golden import EVAL_CASES
 
 
-def test_layer_table_matches_survey_counts():
+def test_layer_table_counts():
     convs = layers.all_convs()
     assert len(convs) == 49 and len(layers.state_dict_keys()) == 333
     assert layers.macs_per_face() == 221_161_984
