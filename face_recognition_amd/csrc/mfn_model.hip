@@ -515,11 +515,15 @@ static int forward(mfn_handle* h, const void* x, int x_is_u8, int B, bool tta, f
     FRA_REQUIRE(h->fused || (!tta && !x_is_u8), FRA_ERR_STATE, "uint8 input and fused flip-TTA need the fused schedule");
     const int nops = (int)h->ops().size();
     const int sl = slice_size(h, B);
-    std::vector<hipEvent_t> ev;
+    struct Events {                                    // destroyed on every way out, error returns included
+        std::vector<hipEvent_t> v;
+        ~Events() { for (auto e : v) if (e) (void)hipEventDestroy(e); }
+    } evs;
+    std::vector<hipEvent_t>& ev = evs.v;
     if (op_ms) {
         FRA_REQUIRE(n_ops_timed >= nops, FRA_ERR_ARG, "op_ms has room for %d ops, model has %d", n_ops_timed, nops);
         for (int i = 0; i < nops; ++i) op_ms[i] = 0.0f;
-        ev.resize(nops + 1);
+        ev.assign(nops + 1, nullptr);
         for (auto& e : ev) FRA_HIP(hipEventCreate(&e));
     }
     for (int b0 = 0; b0 < B; b0 += sl) {
@@ -549,7 +553,6 @@ static int forward(mfn_handle* h, const void* x, int x_is_u8, int B, bool tta, f
             }
         }
     }
-    for (auto& e : ev) (void)hipEventDestroy(e);
     return FRA_OK;
 }
 
