@@ -69,7 +69,7 @@ def kernel_label(name, kind, dt):
                 return f"pw_gemm_kernel<{T}, {c.cin}, {bm}, {nt}>"
             if kind == "dw3x3":
                 return f"dw3x3_kernel<{T}, {c.stride}>"
-    return {"stemdw": f"stemdw_kernel<{T}>", "stem": f"stem_kernel<{T}>", "gdconv7": f"gdconv7_kernel<{T}>", "linear": f"linear_l2norm_kernel<{T}, 16, 1, false>",
+    return {"stemdw": f"stemdw_kernel<{T}>", "stem": f"stem_kernel<{T}>", "gdconv7": f"gdconv7_kernel<{T}>", "linear": f"linear_l2norm_kernel<{T}, 16, 1>",
             "tail": f"tail_kernel<{T}>"}[kind]
 
 

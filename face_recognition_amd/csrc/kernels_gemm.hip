@@ -114,78 +114,37 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const T* __restrict__ A, c
 // ---------------------------------------------------------------------------------------------
 // Embedding head: out f32 [B,E] = l2norm(in[B,512] . w[E,512]^T + bias[E]).
 //   (Flatten + Linear + BatchNorm1d folded + l2_norm: face_model.py:124-129, 19-22)
-//   32 images per block; NWV waves, wave w owns channels [w E/NWV, (w+1) E/NWV); the squared row norm is
-//   reduced over registers, the two lane halves and the waves (in wave order, whatever the batch).  One
-//   32-channel tile per wave where the block size allows: a block streams the whole weight matrix
-//   through one CU, and at batch 1 that stream (a chain of dependent loads per wave) is all there is.
-//   SPLIT (a single group of up to 32 images): the same waves as NWV one-wave blocks (blockIdx.y = wave), so
-//   that the weight matrix streams through NWV compute units at once; such a block cannot see the other
-//   channels' squares, writes its values un-normalised, and l2norm_replay_kernel finishes the rows with the
-//   same additions in the same order -- the result does not depend on which way a batch went.
+//   Two launches.  linear_l2norm_kernel: one wave per (group of 32 images, 32 NTW channels): its K = 512 is 32 MFMA
+//   steps whose weight and activation fragments come straight from memory, all loads in flight at once, so the
+//   weight matrix streams through E / (32 NTW) compute units per image group instead of one; it writes the values
+//   un-normalised, because a wave sees only its own channels' squares.  l2norm_rows_kernel: one wave per image adds
+//   the squares in a fixed order (per (channel group, lane half) in register order, halves, groups in order) and
+//   divides.  Nothing depends on the batch size or on which images share a group.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NWV, int NTW, bool SPLIT>
-__global__ __launch_bounds__(SPLIT ? 64 : NWV * 64) void linear_l2norm_kernel(const T* __restrict__ A,
-                                                                            const T* __restrict__ Wt,
-                                                                            const float* __restrict__ bias,
-                                                                            float* __restrict__ out, int B) {
+template <typename T, int NWV, int NTW>
+__global__ __launch_bounds__(64) void linear_l2norm_kernel(const T* __restrict__ A, const T* __restrict__ Wt,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int B) {
     typedef typename vec8<T>::type V8;
-    constexpr int K = 512, CH = K / 8, E = 32 * NWV * NTW, NT = NWV * 64;
-    __shared__ __attribute__((aligned(16))) char smem[SPLIT ? 16 : 32 * K * 2];
-    __shared__ float red[SPLIT ? 1 : NWV][32];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = SPLIT ? blockIdx.y : tid >> 6;
+    constexpr int K = 512, E = 32 * NWV * NTW;
+    const int lane = threadIdx.x, cg = blockIdx.y;           // cg: channel group
     const int r = lane & 31, h = lane >> 5;
     const int b0 = blockIdx.x * 32;
-    const T* arow = A + (size_t)(b0 + r < B ? b0 + r : B - 1) * K + 8 * h;   // SPLIT: fragments straight from memory
-
-    if constexpr (!SPLIT) {
-        for (int i = tid; i < 32 * CH; i += NT) {
-            const int row = i / CH, c = i - row * CH;
-            int gb = b0 + row;
-            gb = gb < B ? gb : B - 1;
-            const V8 v = *reinterpret_cast<const V8*>(A + (size_t)gb * K + c * 8);
-            *reinterpret_cast<V8*>(smem + ((row * CH + (c ^ swz<CH>(row))) << 4)) = v;
-        }
-        __syncthreads();
-    }
+    const T* arow = A + (size_t)(b0 + r < B ? b0 + r : B - 1) * K + 8 * h;
 
     f32x16 acc[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[nt][g] = 0.0f;
-    const int nbase = wave * 32 * NTW;
-    constexpr int UNR = SPLIT ? 32 : 8;   // SPLIT: every load of the wave's stream in flight at once
-#pragma unroll UNR
+    const int nbase = cg * 32 * NTW;
+#pragma unroll
     for (int s = 0; s < K / 16; ++s) {
-        const int c = 2 * s + h;
-        V8 bfrag;
-        if constexpr (SPLIT) bfrag = *reinterpret_cast<const V8*>(arow + 16 * s);
-        else bfrag = *reinterpret_cast<const V8*>(smem + ((r * CH + (c ^ swz<CH>(r))) << 4));
+        const V8 bfrag = *reinterpret_cast<const V8*>(arow + 16 * s);
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const V8 afrag = *reinterpret_cast<const V8*>(Wt + (size_t)(nbase + nt * 32 + r) * K + s * 16 + h * 8);
             acc[nt] = mfma32(afrag, bfrag, acc[nt]);
         }
-    }
-    float ss = 0.0f;
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const float v = acc[nt][g] + bias[nbase + nt * 32 + acc_row(g, h)];
-            acc[nt][g] = v;
-            ss = fmaf(v, v, ss);
-        }
-    float nrm = 1.0f;
-    if constexpr (!SPLIT) {
-        ss += __shfl_xor(ss, 32, 64);
-        if (h == 0) red[wave][r] = ss;
-        __syncthreads();
-        float tot = red[0][r];
-#pragma unroll
-        for (int w = 1; w < NWV; ++w) tot += red[w][r];
-        nrm = sqrtf(tot);
     }
     const int b = b0 + r;
     if (b < B) {
@@ -195,20 +154,19 @@ __global__ __launch_bounds__(SPLIT ? 64 : NWV * 64) void linear_l2norm_kernel(co
             for (int q = 0; q < 4; ++q) {
                 f32x4 o;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = SPLIT ? acc[nt][4 * q + i] : acc[nt][4 * q + i] / nrm;
+                for (int i = 0; i < 4; ++i) o[i] = acc[nt][4 * q + i] + bias[nbase + nt * 32 + acc_row(4 * q + i, h)];
                 *reinterpret_cast<f32x4*>(out + (size_t)b * E + nbase + nt * 32 + 8 * q + 4 * h) = o;
             }
     }
 }
 
-// Finishes linear_l2norm_kernel<.., SPLIT>: row b of out [B][E] holds the un-normalised values.  One wave per row;
-// lane 2 w + h replays what half h of wave w adds up in the un-split kernel (its tiles in order, its 16 rows of a
-// tile in register order), the halves are added, the waves summed in wave order, and every value is divided by
-// the root of that sum -- bit for bit what the un-split kernel writes.
+// Row b of out [B][E] holds the un-normalised values; one wave per row.  Lane 2 w + h adds the squares of channel
+// group w, half h (channels 32 (w NTW + nt) + acc_row(g, h), nt then g ascending), the halves are added, the groups
+// summed in order, and every value is divided by the root of that sum.
 template <int NWV, int NTW>
-__global__ __launch_bounds__(64) void l2norm_replay_kernel(float* __restrict__ out) {
+__global__ __launch_bounds__(64) void l2norm_rows_kernel(float* __restrict__ out) {
     constexpr int E = 32 * NWV * NTW;
-    static_assert(2 * NWV <= 64, "one lane per (wave, half)");
+    static_assert(2 * NWV <= 64, "one lane per (channel group, half)");
     float* row = out + (size_t)blockIdx.x * E;
     const int lane = threadIdx.x, w = lane >> 1, h = lane & 1;
     float ss = 0.0f;
@@ -278,13 +236,9 @@ int launch_pw(int dt, const void* in, const void* w, const float* bias, const fl
 template <typename T>
 static int launch_linear_t(const T* in, const T* w, const float* bias, float* out, int B, int E, hipStream_t s) {
     const dim3 grid((B + 31) / 32);
-#define FRA_LINEAR(NWV, NTW)                                                                                        \
-    if (B <= 32) {                                                                                                  \
-        hipLaunchKernelGGL((linear_l2norm_kernel<T, NWV, NTW, true>), dim3(1, NWV), dim3(64), 0, s, in, w, bias, out, B); \
-        hipLaunchKernelGGL((l2norm_replay_kernel<NWV, NTW>), dim3(B), dim3(64), 0, s, out);                           \
-    } else {                                                                                                        \
-        hipLaunchKernelGGL((linear_l2norm_kernel<T, NWV, NTW, false>), grid, dim3(NWV * 64), 0, s, in, w, bias, out, B); \
-    }
+#define FRA_LINEAR(NWV, NTW)                                                                                    \
+    hipLaunchKernelGGL((linear_l2norm_kernel<T, NWV, NTW>), dim3(grid.x, NWV), dim3(64), 0, s, in, w, bias, out, B); \
+    hipLaunchKernelGGL((l2norm_rows_kernel<NWV, NTW>), dim3(B), dim3(64), 0, s, out);
     switch (E) {
         case 128: FRA_LINEAR(4, 1) break;
         case 256: FRA_LINEAR(8, 1) break;

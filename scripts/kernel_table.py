@@ -11,7 +11,7 @@ for row in csv.DictReader(open(os.path.join(root, "profiles/r01_kernel_stats.csv
         st["block_kernel<_Float16, %s, %s, %s, %s, %s>" % m.groups()[:5]] = float(row["AverageNs"]) / 1e3
     elif "stemdw_kernelIDF16_" in n: st["stemdw_kernel<_Float16>"] = float(row["AverageNs"]) / 1e3
     elif "tail_kernelIDF16_" in n: st["tail_kernel<_Float16>"] = float(row["AverageNs"]) / 1e3
-    elif "linear_l2norm_kernelIDF16_Li16ELi1ELb0" in n: st["linear_l2norm_kernel<_Float16, 16, 1, false>"] = float(row["AverageNs"]) / 1e3
+    elif "linear_l2norm_kernelIDF16_Li16ELi1E" in n: st["linear_l2norm_kernel<_Float16, 16, 1>"] = float(row["AverageNs"]) / 1e3
 names = {"block_kernel<_Float16, 64, 128, 64, 28, 1>": "`block_kernel` 64â†’128â†’64 @28Â², s1 (conv_3, Ã—4)",
          "block_kernel<_Float16, 128, 256, 128, 14, 1>": "`block_kernel` 128â†’256â†’128 @14Â², s1 (conv_4, Ã—6)",
          "block_kernel<_Float16, 64, 128, 64, 56, 2>": "`block_kernel` 64â†’128â†’64 @56Â², s2 (conv_23, Ã—1)",
@@ -19,7 +19,7 @@ names = {"block_kernel<_Float16, 64, 128, 64, 28, 1>": "`block_kernel` 64â†’128â
          "block_kernel<_Float16, 64, 256, 128, 28, 2>": "`block_kernel` 64â†’256â†’128 @28Â², s2 (conv_34, Ã—1)",
          "block_kernel<_Float16, 128, 512, 128, 14, 2>": "`block_kernel` 128â†’512â†’128 @14Â², s2 (conv_45, Ã—1)",
          "block_kernel<_Float16, 128, 256, 128, 7, 1>": "`block_kernel` 128â†’256â†’128 @7Â², s1 (conv_5, Ã—2)",
-         "linear_l2norm_kernel<_Float16, 16, 1, false>": "`linear_l2norm_kernel`",
+         "linear_l2norm_kernel<_Float16, 16, 1>": "`linear_l2norm_kernel` + `l2norm_rows_kernel`",
          "tail_kernel<_Float16>": "`tail_kernel` (conv_6_sep + conv_6_dw)"}
 tb = tt = ts = 0.0
 for k, v in sorted(r["kernels"].items(), key=lambda kv: -kv[1]["ms"]):
