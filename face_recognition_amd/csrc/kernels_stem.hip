@@ -160,8 +160,18 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, const T* __restrict__
         pv[2] = reinterpret_cast<const f32x4*>(b2)[tid];
         pv[3] = reinterpret_cast<const f32x4*>(s2)[tid];
     }
-    // zero the activation image and the padding plane; planes 0-2 are written in full by the staging loop
-    for (int i = tid; i < ES_BYTES / 16; i += NT) reinterpret_cast<f32x4*>(es)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // zero what the depthwise stage reads of the activation image but the stem stage never writes -- the border slots
+    // 0 and W + 1 of every row and the rows outside the image -- and the padding plane; planes 0-2 are written in
+    // full by the staging loop
+    for (int i = tid; i < RIN * 16; i += NT) {
+        const int ri = i >> 4, u = i & 15;
+        *reinterpret_cast<f32x4*>(es + (ri * PITCH + (u >> 3) * (W + 1)) * 128 + (u & 7) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (row0 < 0)
+        for (int i = tid; i < PITCH * 8; i += NT) reinterpret_cast<f32x4*>(es)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row0 + RIN - 1 >= H)
+        for (int i = tid; i < PITCH * 8; i += NT)
+            reinterpret_cast<f32x4*>(es + (RIN - 1) * PITCH * 128)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = tid; i < NR * PW * 2 / 16; i += NT)
         reinterpret_cast<f32x4*>(lds + OFF_IN + 3 * NR * PW * 2)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     static_assert(9 * 64 / 8 <= NT, "one thread per 16-byte piece of the 3x3 weights");
