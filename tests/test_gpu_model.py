@@ -88,6 +88,15 @@ def test_large_batch_rows_match_small_batches(hip_model, device):
     assert torch.isfinite(full).all()
 
 
+def test_band_configurations_agree_bit_for_bit(hip_model, device):
+    """The block kernels run short bands while those fit the chip in one go (up to 18 or 36 images, depending on
+    the layer) and tall bands beyond: batches on every side of both limits give the same rows."""
+    x = torch.from_numpy(synthetic.make_crops(40, 13)).to(device)
+    want = hip_model(x).cpu()                      # 40: tall bands everywhere
+    for B in (1, 18, 19, 36, 37):
+        assert torch.equal(hip_model(x[:B].contiguous()).cpu(), want[:B]), B
+
+
 def test_fused_and_unfused_schedules_agree(hip_model, device, state_dict_np):
     """One kernel per block vs one kernel per conv: same arithmetic up to summation order."""
     xn = synthetic.make_crops(3, 21)
