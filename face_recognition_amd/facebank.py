@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from pathlib import Path
 from typing import Callable, Optional, Tuple, Union
 
@@ -76,6 +77,9 @@ class Gallery:
         with torch.cuda.device(device):
             if rows is not None and rows.is_cuda and rows.device != device:
                 rows = rows.to(device)
+            if rows is not None and rows.is_cuda:
+                # fb_create packs on the default stream: the rows must have been written by then
+                torch.cuda.current_stream(device).synchronize()
             _lib.check(lib.fb_create(C.byref(h), device.index, rows.data_ptr() if rows is not None else None,
                                      1 if (rows is not None and rows.is_cuda) else 0, n, d,
                                      _lib.DTYPE_BY_NAME[store], self.index_base), "fb_create")
@@ -110,7 +114,8 @@ class Gallery:
 
     def close(self) -> None:
         if getattr(self, "_h", None):
-            _lib.load().fb_destroy(self._h)
+            with torch.cuda.device(self.device):   # the C side frees on the handle's device
+                _lib.load().fb_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -135,20 +140,39 @@ def merge_topk(dist_parts: torch.Tensor, idx_parts: torch.Tensor, k: int) -> Tup
     return dist, idx
 
 
+# (id(tensor), store) -> (weak reference to the tensor, its state when packed, Gallery).  An entry is
+# only valid for the very tensor OBJECT it was built from: a freed facebank's address (and _version 0)
+# is routinely handed to the next same-shaped tensor by the caching allocator, so neither identifies it.
 _gallery_cache = {}
 
 
+def _tensor_state(t: torch.Tensor):
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, str(t.device), t.dtype)
+
+
 def _as_gallery(targets, store: str) -> Gallery:
+    """Device copy of a facebank tensor, cached per tensor object.
+
+    The copy is rebuilt when the tensor object differs or its ``_version`` moved (in-place torch ops).
+    Writes that bypass the version counter (``.data``, kernels outside torch) are not seen: build a
+    ``Gallery`` yourself and ``fill`` it when rows change that way.
+    """
     if isinstance(targets, Gallery):
         return targets
-    key = (targets.data_ptr(), tuple(targets.shape), targets._version, str(targets.device), store)
-    g = _gallery_cache.get(key)
-    if g is None:
-        if len(_gallery_cache) >= 4:
-            _gallery_cache.pop(next(iter(_gallery_cache))).close()
-        dev = targets.device if targets.is_cuda else None
-        g = Gallery(targets, store=store, device=dev)
-        _gallery_cache[key] = g
+    for k in [k for k, (ref, _, _) in _gallery_cache.items() if ref() is None]:   # owners that died
+        _gallery_cache.pop(k)[2].close()
+    key = (id(targets), store)
+    hit = _gallery_cache.get(key)
+    if hit is not None:
+        ref, state, g = hit
+        if ref() is targets and state == _tensor_state(targets):
+            return g
+        _gallery_cache.pop(key)[2].close()
+    if len(_gallery_cache) >= 4:
+        _gallery_cache.pop(next(iter(_gallery_cache)))[2].close()
+    dev = targets.device if targets.is_cuda else None
+    g = Gallery(targets, store=store, device=dev)
+    _gallery_cache[key] = (weakref.ref(targets), _tensor_state(targets), g)
     return g
 
 

@@ -32,18 +32,34 @@ def match_broadcast(source_embs: torch.Tensor, targets: torch.Tensor, threshold:
 
 def l2_topk_bruteforce(queries: np.ndarray, gallery: np.ndarray, k: int = 5, block: int = 4096
                        ) -> Tuple[np.ndarray, np.ndarray]:
-    """Exact squared-L2 top-k in float64: (dist f64[Q,k] ascending, idx i64[Q,k]); ties -> lowest index."""
+    """Exact squared-L2 top-k in float64: (dist f64[Q,k] ascending, idx i64[Q,k]); ties -> lowest index.
+
+    The gallery is converted to float64 one block at a time and each block contributes only its k
+    smallest candidates per query (all candidates of a row whose k-th value is tied), so a 10^6-row
+    gallery costs seconds and a block's worth of memory."""
     q = np.asarray(queries, dtype=np.float64)
-    g = np.asarray(gallery, dtype=np.float64)
     qn = np.sum(q * q, axis=1)[:, None]
-    best_d = np.full((q.shape[0], 0), np.inf)
-    best_i = np.zeros((q.shape[0], 0), dtype=np.int64)
-    for s in range(0, g.shape[0], block):
-        gb = g[s:s + block]
+    nq = q.shape[0]
+    best_d = np.full((nq, 0), np.inf)
+    best_i = np.zeros((nq, 0), dtype=np.int64)
+    for s in range(0, gallery.shape[0], block):
+        gb = np.asarray(gallery[s:s + block], dtype=np.float64)
         d = qn + np.sum(gb * gb, axis=1)[None, :] - 2.0 * (q @ gb.T)
-        ids = np.broadcast_to(np.arange(s, s + gb.shape[0], dtype=np.int64)[None, :], d.shape)
-        cd = np.concatenate([best_d, d], axis=1)
-        ci = np.concatenate([best_i, ids], axis=1)
+        nb = gb.shape[0]
+        if nb > 4 * k:
+            part = np.argpartition(d, k - 1, axis=1)[:, :k]
+            kth = np.take_along_axis(d, part, axis=1).max(axis=1)
+            tied = np.nonzero((d <= kth[:, None]).sum(axis=1) > k)[0]   # rows whose k-th value repeats
+            cand_d = np.take_along_axis(d, part, axis=1)
+            cand_i = part.astype(np.int64) + s
+            for r in tied:                                             # keep the lowest indices of the tie
+                o = np.lexsort((np.arange(nb), d[r]))[:k]
+                cand_d[r], cand_i[r] = d[r, o], o + s
+        else:
+            cand_d = d
+            cand_i = np.broadcast_to(np.arange(s, s + nb, dtype=np.int64)[None, :], d.shape)
+        cd = np.concatenate([best_d, cand_d], axis=1)
+        ci = np.concatenate([best_i, cand_i], axis=1)
         order = np.lexsort((ci, cd), axis=1)[:, :k]          # primary key distance, then index
         best_d = np.take_along_axis(cd, order, axis=1)
         best_i = np.take_along_axis(ci, order, axis=1)

@@ -45,6 +45,27 @@ def test_get_feature_and_10fold_vs_oracle(hip_model, device, state_dict_np):
     assert cosine_rows(fl2.numpy(), want).min() >= 0.9999
 
 
+def test_accuracy_within_point_one_on_gpu_embeddings(hip_model, device, state_dict_np):
+    """The 0.1-pt criterion on REAL GPU embeddings at a size where it can fail: 2,000 synthetic pairs
+    (one pair = 0.05 pt; fold = i // (P/10) as the LFW / CFP-FP / AgeDB loaders assign it) whose noise
+    level puts the 10-fold accuracy in the low 90s, where many pairs sit near the threshold.  Embedded
+    once by the HIP forward through getFeature (bs 50, flip) and once by the fp32 oracle on the host."""
+    pairs = 2000
+    left, right, ds = synthetic.pair_crops(pairs, seed=16, noise=0.45)
+    fl, fr = Evaluation.getFeature(hip_model, _loader(left, right, 50), device, flip=True)
+    embed = lambda x: mobilefacenet_ref.forward(state_dict_np, x)      # noqa: E731
+    ol, orr = evaluation_ref.get_feature(embed, _loader(left, right, 250), flip=True)
+    assert cosine_rows(fl.numpy(), ol.numpy()).min() >= 0.9999
+    assert cosine_rows(fr.numpy(), orr.numpy()).min() >= 0.9999
+    for method in ("l2_distance", "cos_distance"):
+        acc, thr = Evaluation.evaluation_10_fold(fl, fr, ds, method)
+        oacc, othr = evaluation_ref.evaluation_10_fold(ol.numpy(), orr.numpy(), ds.folds, ds.flags, method)
+        print(method, "GPU acc %.3f %% vs oracle %.3f %%; thr %.4f vs %.4f" %
+              (acc.mean() * 100, oacc.mean() * 100, thr.mean(), othr.mean()))
+        assert 70.0 < oacc.mean() * 100 < 99.5, "the set must leave pairs near the threshold"
+        assert abs(acc.mean() - oacc.mean()) * 100 <= 0.1 + 1e-9
+
+
 def test_accuracy_within_point_one_on_perturbed_features(device):
     """Features perturbed by the error level the fp16 path shows (cosine 0.9999 ~ 1.4 % relative
     noise is the allowed worst case; measured is ~10x smaller) keep 10-fold accuracy within 0.1 pt."""

@@ -64,11 +64,10 @@ def _check_topk(dist, idx, queries, gallery, k, tie_tol):
     assert (np.diff(dist, axis=1) >= -1e-6).all()
     mism = idx[:, 0] != bi[:, 0]
     if mism.any():
-        g64 = gallery.astype(np.float64)
         q64 = queries.astype(np.float64)
-        d_mine = ((q64[mism] - g64[idx[mism, 0]]) ** 2).sum(1)
+        d_mine = ((q64[mism] - gallery[idx[mism, 0]].astype(np.float64)) ** 2).sum(1)
         assert (np.abs(d_mine - bd[mism, 0]) < tie_tol).all(), "top-1 differs beyond the near-tie tolerance"
-    true_d = ((queries.astype(np.float64)[:, None, :] - gallery.astype(np.float64)[idx]) ** 2).sum(-1)
+    true_d = ((queries.astype(np.float64)[:, None, :] - gallery[idx].astype(np.float64)) ** 2).sum(-1)
     assert np.abs(true_d - dist).max() < tie_tol
     # every returned row is at least as close as the true k-th neighbour, up to the near-tie tolerance
     assert (true_d <= bd[:, k - 1:k] + tie_tol).all()
@@ -91,6 +90,52 @@ def test_topk_f16_vs_bruteforce(device, Q, N, k):
     assert (idx.cpu().numpy()[planted, 0] == truth[planted]).all()
     print(f"Q={Q} N={N} k={k}: top-1 mismatch {mism:.4f}, top-{kk} recall {recall:.4f}")
     assert recall > 0.99   # fp16 rounding may swap the 5th and 6th neighbour when they are near-tied
+
+
+def test_topk_f16_one_million_rows_vs_bruteforce(device):
+    """The 10k x 1M top-5 configuration's gallery size: 256 queries (half planted, half random -- the random
+    half is where near-ties live) against the float64 brute force over all 10^6 rows."""
+    N, Q, k = 1_000_000, 256, 5
+    g = synthetic.unit_rows(N, 512, seed=3)
+    q, truth = synthetic.planted_queries(g, Q, seed=4, target_cos=0.7)
+    gal = Gallery(None, n=N, d=512, store="f16", device=device)
+    for lo in range(0, N, 250_000):                      # host rows go through the library's bounce buffer
+        gal.fill(lo, torch.from_numpy(g[lo:lo + 250_000]))
+    dist, idx = gal.search(torch.from_numpy(q).to(device), k)
+    mism, recall = _check_topk(dist, idx, q, g, k, 1e-3)
+    planted = truth >= 0
+    assert (idx.cpu().numpy()[planted, 0] == truth[planted]).all()
+    rnd = ~planted
+    bd, bi = mref.l2_topk_bruteforce(q[rnd], g, k)
+    rnd_recall = np.mean([len(set(a) & set(b)) / k for a, b in zip(idx.cpu().numpy()[rnd].tolist(), bi.tolist())])
+    print(f"1M rows: top-1 mismatch {mism:.4f} (all inside the 1e-3 near-tie band), top-5 recall {recall:.4f}, "
+          f"random half {rnd_recall:.4f}")
+    assert recall > 0.98 and rnd_recall > 0.97
+    gal.close()
+
+
+def test_gallery_cache_follows_the_tensor_object(device):
+    """match_facebank / topk_search keep a device copy per facebank TENSOR OBJECT.  A facebank that is freed
+    and replaced by another of the same shape usually gets the same address from the caching allocator
+    (with _version 0 again): the new rows must be matched, not the old copy."""
+    a = torch.from_numpy(synthetic.unit_rows(5, 512, seed=30)).to(device)
+    b_host = torch.from_numpy(synthetic.unit_rows(5, 512, seed=31))
+    q = b_host[[3]].to(device)
+    _, ia, _ = match_facebank(a[[2]].clone(), a)
+    assert int(ia[0]) == 2
+    addr = a.data_ptr()
+    del a
+    b = b_host.to(device)
+    reused = b.data_ptr() == addr
+    mn, ib, _ = match_facebank(q, b)
+    assert int(ib[0]) == 3 and float(mn[0]) < 1e-6, f"matched a stale copy (address reused: {reused})"
+    d, i = topk_search(q, b, k=1, store="f32")
+    assert int(i[0, 0]) == 3
+    # in-place updates through torch move _version: the copy is rebuilt
+    b[3] = b[0]
+    mn2, _, _ = match_facebank(q, b)
+    assert float(mn2[0]) > 0.5               # the row q was taken from is gone
+    print("allocator handed the old address back:", reused)
 
 
 def test_topk_f32_exact(device):

@@ -88,6 +88,21 @@ def test_large_batch_rows_match_small_batches(hip_model, device):
     assert torch.isfinite(full).all()
 
 
+def test_batch_1024_rows_match_small_batches(hip_model, device):
+    """The benchmark's batch (1024 crops): the block kernels split it into groups of images per resident
+    workgroup differently from any smaller batch; rows must not depend on that."""
+    B = 1024
+    x = torch.from_numpy(synthetic.make_crops(64, 17)).to(device).repeat(16, 1, 1, 1).contiguous()
+    x += torch.linspace(-0.25, 0.25, B, device=device).view(B, 1, 1, 1)
+    full = hip_model(x).cpu()
+    assert torch.isfinite(full).all()
+    for lo in (0, 3, 255, 256, 509, 767, 1017):
+        part = hip_model(x[lo:lo + 7]).cpu()
+        assert torch.equal(full[lo:lo + 7], part), lo
+    mid = hip_model(x[300:500].contiguous()).cpu()          # 200 crops: the reference harness's 4 x bs 50
+    assert torch.equal(full[300:500], mid)
+
+
 def test_band_configurations_agree_bit_for_bit(hip_model, device):
     """The block kernels run short bands while those fit the chip in one go (up to 18 or 36 images, depending on
     the layer) and tall bands beyond: batches on every side of both limits give the same rows."""
