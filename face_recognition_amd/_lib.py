@@ -54,6 +54,7 @@ SIGNATURES = {
     "fb_export_packed": (_I, [_P, _L, _L, _P, _I, _P, _I]),
     "fb_import_packed": (_I, [_P, _L, _L, _P, _I, _P, _I]),
     "fb_search_l2_topk": (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    "fb_search_l2_topk_noalloc": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "fb_merge_topk": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "fb_threshold_score": (_I, [_P, _P, _P, _I, _D, _P]),
     "fb_destroy": (_I, [_P]),

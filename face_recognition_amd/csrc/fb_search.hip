@@ -530,9 +530,36 @@ static int fill_rows(fb_handle* h, int64_t row0, const float* src, int is_device
     return rc;
 }
 
+// Scratch of one search: `fixed` == nullptr takes (and grows) the handle's own block; otherwise the search must
+// fit the `cap` bytes at `fixed` and nothing is allocated.
+static int take_scratch(fb_handle* h, size_t need, char* fixed, size_t cap, char** out) {
+    if (fixed) {
+        FRA_REQUIRE(need <= cap, FRA_ERR_ARG,
+                    "fb_search_l2_topk_noalloc: this search needs %zu bytes of scratch, the static array holds %zu; "
+                    "use fb_search_l2_topk (fewer queries, or a smaller fp32 gallery, fit)", need, cap);
+        *out = fixed;
+        return FRA_OK;
+    }
+    int rc = ensure_scratch(h, need);
+    if (rc) return rc;
+    *out = static_cast<char*>(h->scratch);
+    return FRA_OK;
+}
+
+template <typename T, int KSV>
+static int launch_search(const dim3 grid, size_t lds, hipStream_t s, const T* G, const float* negh, const T* qh,
+                         const float* qn, float* pd, int* pi, int tiles, int tps, int QT, int S, int Qpad, int index_base) {
+    static std::atomic<uint64_t> lds_set;      // per instantiation: devices whose LDS limit is raised
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&search_kernel<T, KSV>), (int)lds, lds_set)) return rc;
+    hipLaunchKernelGGL((search_kernel<T, KSV>), grid, dim3(512), lds, s, G, negh, qh, qn, pd, pi, tiles, tps, QT, S, Qpad,
+                       index_base);
+    FRA_HIP(hipGetLastError());
+    return FRA_OK;
+}
+
 template <typename T>
 static int search_packed(fb_handle* h, const float* queries, int Q, int k, float* dist_out, int32_t* idx_out,
-                         hipStream_t s) {
+                         hipStream_t s, char* fixed, size_t cap) {
     const int D = h->D;
     const int QT = (Q + BQ - 1) / BQ, Qpad = QT * BQ;
     const int tiles = (int)(h->Npad / BG);
@@ -550,9 +577,11 @@ static int search_packed(fb_handle* h, const float* queries, int Q, int k, float
            off_pd = align_up(off_qn + (size_t)Qpad * 4, 256),
            off_pi = align_up(off_pd + (size_t)P * Qpad * KS * 4, 256),
            total = align_up(off_pi + (size_t)P * Qpad * KS * 4, 256);
-    int rc = ensure_scratch(h, total);
+    char* sc = nullptr;
+    int rc = take_scratch(h, total, fixed, cap, &sc);
     if (rc) return rc;
-    char* sc = static_cast<char*>(h->scratch);
+    // every byte of these four arrays that a later kernel reads is written by an earlier kernel of this
+    // call (all Qpad query rows, all P lists of every query), so stale scratch contents are harmless
     T* qh = reinterpret_cast<T*>(sc + off_qh);
     float* qn = reinterpret_cast<float*>(sc + off_qn);
     float* pd = reinterpret_cast<float*>(sc + off_pd);
@@ -561,20 +590,12 @@ static int search_packed(fb_handle* h, const float* queries, int Q, int k, float
     hipLaunchKernelGGL(prep_queries_kernel<T>, dim3((Qpad + 3) / 4), dim3(256), 0, s, queries, qh, qn, Q, Qpad, D);
     FRA_HIP(hipGetLastError());
     const size_t lds = 3 * (size_t)SEARCH_BUF_BYTES;
-    const dim3 grid((unsigned)(QT * S)), block(512);
+    const dim3 grid((unsigned)(QT * S));
     const T* G = static_cast<const T*>(h->rows);
-#define FRA_LAUNCH_SEARCH(KSV)                                                                                   \
-    do {                                                                                                         \
-        FRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&search_kernel<T, KSV>),                       \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
-        hipLaunchKernelGGL((search_kernel<T, KSV>), grid, block, lds, s, G, h->negh, qh, qn, pd, pi, tiles, tps, \
-                           QT, S, Qpad, (int)h->index_base);                                                     \
-    } while (0)
-    if (KS == 1) FRA_LAUNCH_SEARCH(1);
-    else if (KS == 5) FRA_LAUNCH_SEARCH(5);
-    else FRA_LAUNCH_SEARCH(8);
-#undef FRA_LAUNCH_SEARCH
-    FRA_HIP(hipGetLastError());
+    if (KS == 1) rc = launch_search<T, 1>(grid, lds, s, G, h->negh, qh, qn, pd, pi, tiles, tps, QT, S, Qpad, (int)h->index_base);
+    else if (KS == 5) rc = launch_search<T, 5>(grid, lds, s, G, h->negh, qh, qn, pd, pi, tiles, tps, QT, S, Qpad, (int)h->index_base);
+    else rc = launch_search<T, 8>(grid, lds, s, G, h->negh, qh, qn, pd, pi, tiles, tps, QT, S, Qpad, (int)h->index_base);
+    if (rc) return rc;
     hipLaunchKernelGGL(select_topk_kernel, dim3(Q), dim3(256), 0, s, pd, pi, P, (long)Qpad * KS, (long)KS, KS, 0, k,
                        dist_out, idx_out);
     FRA_HIP(hipGetLastError());
@@ -582,11 +603,12 @@ static int search_packed(fb_handle* h, const float* queries, int Q, int k, float
 }
 
 static int search_f32(fb_handle* h, const float* queries, int Q, int k, float* dist_out, int32_t* idx_out,
-                      hipStream_t s) {
+                      hipStream_t s, char* fixed, size_t cap) {
     const size_t bytes = (size_t)Q * h->N * 4;
-    int rc = ensure_scratch(h, align_up(bytes, 256));
+    char* sc = nullptr;
+    int rc = take_scratch(h, align_up(bytes, 256), fixed, cap, &sc);
     if (rc) return rc;
-    float* dist = static_cast<float*>(h->scratch);
+    float* dist = reinterpret_cast<float*>(sc);
     const long pairs = (long)Q * h->N;
     FRA_REQUIRE((pairs + 3) / 4 < 2147483647L, FRA_ERR_ARG, "fb_search: Q*N too large for the fp32 gallery path");
     hipLaunchKernelGGL(l2dist_f32_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, queries,
@@ -596,6 +618,33 @@ static int search_f32(fb_handle* h, const float* queries, int Q, int k, float* d
     hipLaunchKernelGGL(select_topk_kernel, dim3(Q), dim3(256), 0, s, dist, (const int*)nullptr, 1, 0L, (long)h->N,
                        (int)h->N, (int)h->index_base, k, dist_out, idx_out);
     FRA_HIP(hipGetLastError());
+    return FRA_OK;
+}
+
+static int search_any(fb_handle* h, const float* queries, int Q, int k, float* dist_out, int32_t* idx_out,
+                      hipStream_t s, char* fixed, size_t cap) {
+    if (h->store == FRA_F32) return search_f32(h, queries, Q, k, dist_out, idx_out, s, fixed, cap);
+    if (h->store == FRA_F16) return search_packed<f16>(h, queries, Q, k, dist_out, idx_out, s, fixed, cap);
+    return search_packed<bf16>(h, queries, Q, k, dist_out, idx_out, s, fixed, cap);
+}
+
+// ---- scratch of the entry point that allocates nothing ----------------------------------------------
+// One array per GPU the library runs on, held until the process ends.  The name is a host-side stand-in:
+// only the address hipGetSymbolAddress returns (with that GPU current) may be handed to kernels.
+static const size_t STATIC_SCRATCH_BYTES = (size_t)8 << 20;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+static std::atomic<void*> static_scratch_of[64];   // per device: device address of `scratch`, nullptr = not asked yet
+
+// device address of this GPU's copy of `scratch`; `device` must be the current device
+static int static_scratch_ptr(int device, char** out) {
+    FRA_REQUIRE(device >= 0 && device < 64, FRA_ERR_ARG, "static scratch: device %d not in [0,64)", device);
+    void* p = static_scratch_of[device].load(std::memory_order_acquire);
+    if (!p) {
+        FRA_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        FRA_REQUIRE(p != nullptr, FRA_ERR_HIP, "static scratch: hipGetSymbolAddress returned a null address");
+        static_scratch_of[device].store(p, std::memory_order_release);
+    }
+    *out = static_cast<char*>(p);
     return FRA_OK;
 }
 
@@ -620,6 +669,10 @@ int fb_create(fb_handle** out, int device, const float* gallery, int gallery_is_
     FRA_HIP(hipGetDeviceCount(&count));
     FRA_REQUIRE(device >= 0 && device < count, FRA_ERR_ARG, "fb_create: device %d not in [0,%d)", device, count);
     FRA_HIP(hipSetDevice(device));
+    if (device < 64) {                      // set-up: this GPU's address of the static scratch array
+        char* unused = nullptr;
+        if (int rc = static_scratch_ptr(device, &unused)) return rc;
+    }
     fb_handle* h = new fb_handle();
     h->device = device; h->N = N; h->D = D; h->store = store_dtype; h->index_base = index_base;
     hipError_t e;
@@ -711,10 +764,18 @@ int fb_search_l2_topk(fb_handle* h, const float* queries, int Q, int k, float* d
     FRA_REQUIRE(Q > 0, FRA_ERR_ARG, "fb_search: Q=%d", Q);
     FRA_REQUIRE(k >= 1 && k <= 8, FRA_ERR_ARG, "fb_search: k=%d not in [1,8]", k);
     FRA_HIP(hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream;
-    if (h->store == FRA_F32) return search_f32(h, queries, Q, k, dist_out, idx_out, s);
-    if (h->store == FRA_F16) return search_packed<f16>(h, queries, Q, k, dist_out, idx_out, s);
-    return search_packed<bf16>(h, queries, Q, k, dist_out, idx_out, s);
+    return search_any(h, queries, Q, k, dist_out, idx_out, (hipStream_t)stream, nullptr, 0);
+}
+
+int fb_search_l2_topk_noalloc(fb_handle* h, const float* queries, int Q, int k, float* dist_out, int32_t* idx_out,
+                              fra_stream stream) {
+    FRA_REQUIRE(h && queries && dist_out && idx_out, FRA_ERR_ARG, "fb_search_l2_topk_noalloc: null pointer");
+    FRA_REQUIRE(Q > 0, FRA_ERR_ARG, "fb_search_l2_topk_noalloc: Q=%d", Q);
+    FRA_REQUIRE(k >= 1 && k <= 8, FRA_ERR_ARG, "fb_search_l2_topk_noalloc: k=%d not in [1,8]", k);
+    FRA_HIP(hipSetDevice(h->device));
+    char* sc = nullptr;
+    if (int rc = static_scratch_ptr(h->device, &sc)) return rc;   // found at fb_create; a lookup, not an allocation
+    return search_any(h, queries, Q, k, dist_out, idx_out, (hipStream_t)stream, sc, STATIC_SCRATCH_BYTES);
 }
 
 int fb_merge_topk(const float* dist_in, const int32_t* idx_in, int R, int Q, int k, float* dist_out,

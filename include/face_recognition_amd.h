@@ -90,7 +90,8 @@ int mfn_workspace_bytes_ex(const mfn_handle* h, int max_batch, int tta, size_t* 
 int mfn_forward_timed(mfn_handle* h, const float* x_nchw, int B, float* out, void* workspace,
                       size_t workspace_bytes, fra_stream stream, float* op_ms, int n_ops);
 int mfn_op_count(const mfn_handle* h);
-/* kind: 0 stem, 1 depthwise 3x3, 2 pointwise, 3 gdconv 7x7, 4 linear+l2norm, 5 fused block, 6 fused stem + first depthwise.  flops / bytes are the
+/* kind: 0 stem, 1 depthwise 3x3, 2 pointwise, 3 gdconv 7x7, 4 linear+l2norm, 5 fused block, 6 fused stem + first depthwise,
+ * 7 fused tail (conv_6_sep + conv_6_dw).  flops / bytes are the
  * algorithmic work and HBM traffic (activations read + written) of the op for ONE image; weight_bytes
  * are its parameters, read once per launch whatever the batch. */
 int mfn_op_info(const mfn_handle* h, int op, char* name, int name_cap, int* kind, double* flops_per_image,
@@ -169,6 +170,18 @@ int fb_reserve(fb_handle* h, int max_queries);
  * Generalises  minimum, min_idx = torch.min(dist, dim=1)  of cam_demo.py:97-99. */
 int fb_search_l2_topk(fb_handle* h, const float* queries, int Q, int k, float* dist_out, int32_t* idx_out,
                       fra_stream stream);
+
+/* fb_search_l2_topk for callers that cannot allocate (code under hipGraph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results bit
+ * for bit, but the scratch the search kernels need (16-bit queries, |q|^2, per-split partial top-k lists;
+ * for fp32 galleries the Q x N distance matrix) lives in an 8 MiB array that is part of the library's
+ * device image, one copy per GPU, kept until the process ends; the call allocates and frees nothing.
+ * A search that needs more than 8 MiB of scratch is refused with FRA_ERR_ARG (the message states the
+ * bytes needed): 16-bit galleries take up to 256 queries at any k and any gallery size (512 at k <= 5);
+ * fp32 galleries take Q * N <= 2,097,152.  Nothing in the array has to start at zero.  All calls on one
+ * GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race. */
+int fb_search_l2_topk_noalloc(fb_handle* h, const float* queries, int Q, int k, float* dist_out, int32_t* idx_out,
+                              fra_stream stream);
 
 /* Merge R lists of k candidates per query (dist_in / idx_in dev [R,Q,k], e.g. the result of an
  * all-gather of per-shard fb_search_l2_topk outputs) into the k best, same ordering rules. */
