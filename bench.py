@@ -60,6 +60,8 @@ def kernel_label(name, kind, dt):
     T = "_Float16" if dt == "f16" else "__bf16"
     if kind == "block":
         b = next(b for b in layers.BLOCKS if b.prefix == name)
+        if name.startswith("conv_4."):
+            return f"rblock_kernel<{T}, {b.cin}, {b.cexp}, {b.hin}>"
         return f"block_kernel<{T}, {b.cin}, {b.cexp}, {b.cout}, {b.hin}, {b.stride}>"
     for c in layers.all_convs():
         if c.prefix == name:
@@ -83,13 +85,17 @@ def per_kernel_profile(net, x, reps, dt):
         acc = ms if acc is None else acc + ms
     ms = acc / reps
     B = x.shape[0]
+    plan = net.launch_plan(B)       # op -> the op whose launch covers it (a chain of blocks is one launch)
     groups = {}
-    for (name, kind, flops, nbytes, wbytes), t in zip(table, ms):
-        g = groups.setdefault(kernel_label(name, kind, dt), dict(kind=kind, launches=0, ms=0.0, bytes=0.0, flops=0.0))
-        g["launches"] += 1
+    for i, ((name, kind, flops, nbytes, wbytes), t) in enumerate(zip(table, ms)):
+        g = groups.setdefault(kernel_label(name, kind, dt), dict(kind=kind, launches=0, ops=0, ms=0.0, bytes=0.0, flops=0.0))
+        g["ops"] += 1
         g["ms"] += float(t)
-        g["bytes"] += nbytes * B + wbytes
         g["flops"] += flops * B
+        g["bytes"] += wbytes
+        if plan[i] == i:            # only a launch's first op reads activations from HBM and only its last writes them;
+            g["launches"] += 1      # the blocks of a chain have equal shapes, so one op's in + out is the launch's
+            g["bytes"] += nbytes * B
     return groups, float(ms.sum())
 
 

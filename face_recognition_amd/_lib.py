@@ -31,6 +31,8 @@ SIGNATURES = {
     "mfn_workspace_bytes": (_I, [_P, _I, C.POINTER(C.c_size_t)]),
     "mfn_set_batch_chunk": (_I, [_P, _I]),
     "mfn_set_fused": (_I, [_P, _I]),
+    "mfn_set_chain": (_I, [_P, _I]),
+    "mfn_launch_plan": (_I, [_P, _I, C.POINTER(_I), _I]),
     "mfn_forward": (_I, [_P, _P, _I, _P, _P, C.c_size_t, _P]),
     "mfn_forward_ex": (_I, [_P, _P, _I, _I, _I, _P, _P, C.c_size_t, _P]),
     "mfn_workspace_bytes_ex": (_I, [_P, _I, _I, C.POINTER(C.c_size_t)]),
@@ -44,6 +46,9 @@ SIGNATURES = {
     "mfn_op_dw3x3": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mfn_op_pw": (_I, [_I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "mfn_op_block": (_I, [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "mfn_rblock_package_bytes": (_L, [_I, _I]),
+    "mfn_pack_rblock": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfn_op_rblock": (_I, [_I, _I, _I, _I, _P, _P, _I, _P, _I, _P]),
     "mfn_op_gdconv7": (_I, [_I, _P, _P, _P, _P, _I, _I, _P]),
     "mfn_op_tail": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "mfn_op_linear_l2norm": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libface_recognition_amd.so")
-SOURCES = ["api.cpp", "kernels_conv.hip", "kernels_gemm.hip", "kernels_block.hip", "kernels_stem.hip", "mfn_model.hip", "fb_search.hip", "ev_fold.hip", "fa_align.hip", "kernels_tail.hip"]
+SOURCES = ["api.cpp", "kernels_conv.hip", "kernels_gemm.hip", "kernels_block.hip", "kernels_rblock.hip", "kernels_stem.hip", "mfn_model.hip", "fb_search.hip", "ev_fold.hip", "fa_align.hip", "kernels_tail.hip"]
 ARCH = "gfx950"
 
 
@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "face_recognition_amd.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "block_stages.h"), os.path.join(HERE, "..", "include", "face_recognition_amd.h")]
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-x", "hip", "-Wall", "-Wno-unused-function",
              # keep scalar f16*f16+f32 FMAs (v_fma_mix_f32) instead of convert + packed-f32 FMA
              "-fno-slp-vectorize"]

@@ -134,6 +134,40 @@ inline size_t w3_image_index(int co, int pos, int cout) {
     return (((size_t)c * 2 * cout + row) * 4 + unit) * 8 + j;
 }
 int launch_block(int dt, const BlockParams& p, const void* x, void* out, int B, hipStream_t s);
+
+// ---- residual blocks with the activation kept in registers between blocks (kernels_rblock.hip) ----------------
+// Everything one 64-channel slice of one block needs travels as ONE package, stored in global memory exactly as it
+// sits in LDS (padding included), so a package is copied by 1 KB LDS-DMA pieces:
+//   W1 image | W3 image | b1 | s1 | b2 | s2 | 3x3 weight image | b3      (rounded up to whole pieces)
+// W1 image: 4 channel tiles x 32 rows of C/2 elements + one 16-byte unit of padding; row 16 p + m of tile t holds,
+//   for expanded channel 64 c + 16 t + m, the units [ks][g >> 1] of the k-groups g with g & 1 == p, where element j
+//   of k-step ks, k-group g is INPUT channel rb_in_channel(ks, g, j) -- the order in which a lane of the project
+//   stage holds its output channels, so that a block's output is the next block's expand operand as it stands.
+// b1, s1 (slope - 1): natural channel order inside the slice.  Position of expanded channel 16 t + 4 g + i of the
+// slice on the depthwise / project side: 16 g + 4 t + i (rb_pos); b2, s2, the 3x3 weight image (13 rows of
+// 64 positions + 32 bytes: taps 0..8, tap 2 again, three zero rows) and the W3 image's columns use positions.
+// W3 image: 2 C rows of 64 + 16 bytes; row 32 n + 16 (g & 1) + m holds, for output channel 16 n + m, units
+// [pair P][g >> 1]; element j of a unit is position 32 P + 4 g + j (j < 4) or 32 P + 16 + 4 g + (j - 4).
+template <int C> struct RbPkg {
+    static constexpr int PW1 = C + 16, W1_BYTES = 128 * PW1;
+    static constexpr int PW3 = 80, W3_BYTES = 2 * C * PW3, OFF_W3 = W1_BYTES;
+    static constexpr int OFF_B1 = OFF_W3 + W3_BYTES, OFF_S1 = OFF_B1 + 256, OFF_B2 = OFF_S1 + 256, OFF_S2 = OFF_B2 + 256;
+    static constexpr int PW2 = 160, OFF_W2 = OFF_S2 + 256, OFF_B3 = OFF_W2 + 13 * PW2;
+    static constexpr int RAW = OFF_B3 + C * 4;
+    static constexpr int BYTES = (RAW + 1023) / 1024 * 1024, PIECES = BYTES / 1024;
+};
+inline int rb_in_channel(int ks, int g, int j) { return 16 * (2 * ks + (j >> 2)) + 4 * g + (j & 3); }
+inline int rb_pos(int e_local) { return 16 * ((e_local >> 2) & 3) + 4 * (e_local >> 4) + (e_local & 3); }
+// bytes of the packages of one block (cexp / 64 slices); 0 for an unsupported width
+size_t rblock_package_bytes(int c, int cexp);
+// folded weights in natural order (w1 [cexp][c], w2 [cexp][9], w3 [c][cexp]; s1 / s2 = PReLU slopes) -> packages
+int pack_rblock(int dt, int c, int cexp, const float* w1, const float* b1, const float* s1, const float* w2,
+                const float* b2, const float* s2, const float* w3, const float* b3, void* out);
+// `nblk` consecutive blocks (packages back to back at wp) on x -> out, T NHWC [B][h][h][c]; nblk > 1 keeps the
+// activation in registers between blocks (whole-image workgroups); out may be x
+int launch_rblock(int dt, int c, int cexp, int h, const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s);
+// true when `nblk` > 1 blocks of this shape should run as one launch for a batch of B images
+bool rblock_chain_pays(int c, int cexp, int h, int B);
 // fused head: stem conv (3->64, 3x3 s2, PReLU) + depthwise 3x3 (64 ch, PReLU) -> out T NHWC [B,56,56,64].
 // x: n_src crops, f32 NCHW in [-1,1] or (x_is_u8) uint8 HWC; images n_src..B-1 are mirrored copies of images 0..B-n_src-1
 struct StemDwParams {

@@ -1,0 +1,465 @@
+// Residual inverted-residual blocks (stride 1, C -> CEXP -> C, + x) with the activation kept in REGISTERS
+// from block to block.  (reference: Residual / Depth_Wise.forward, face_model.py:55-75)
+//
+// Same three stages per 64-channel slice as kernels_block.hip -- expand GEMM + PReLU into an LDS image,
+// 3x3 depthwise conv on the matrix cores, project GEMM accumulated in registers -- with two changes that let a
+// block's output feed the next block without leaving the lane that computed it:
+//
+//  * Pixel tiles are row aligned on BOTH sides.  A tile is 32 lanes' worth of whole image rows (two 16-lane
+//    subtiles; a row of 14 uses 14 of its 16 lanes), and wave w owns the same tile as expand input and as
+//    project output.  The halo rows a band needs above and below are a tile of their own, expanded by another
+//    wave.
+//  * The expand GEMM runs on 16x16x32 MFMAs with pixels as columns, like the project GEMM whose result it
+//    consumes.  A project lane (pixel m, k-group g) ends up with output channels 16 n + 4 g + i (n < C/16,
+//    i < 4).  The expand GEMM's K order is free, so k-step ks, k-group g, element j is DEFINED as channel
+//    16 (2 ks + (j >> 2)) + 4 g + (j & 3): exactly what that lane holds.  The expand weights are stored with
+//    their columns in that order (pack_rblock), and
+//        x_next = round(acc + x + b3)
+//    is the whole epilogue: no LDS staging, no shortcut read, no global round trip.  With whole-image
+//    workgroups (TR == H) `nblk` blocks run back to back on an image; only the first block reads global
+//    memory and only the last writes it.
+//
+// Every per-slice input (both weight matrices, biases, slopes, the 3x3 weights) arrives as one package by
+// LDS-DMA into the buffer the previous slice does not use; the packages of consecutive blocks follow each other
+// in memory, so the weight stream simply continues across block boundaries.
+//
+// A band of TR < H rows (one block per launch) runs the same arithmetic per output value -- the same MFMA
+// shapes, operand order and roundings -- so results do not depend on which configuration a batch size selects.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "block_stages.h"
+
+namespace fra {
+
+// ---- expand stage: E[16-channel tile][pixels] = PReLU(W1 . X + b1) for tiles T0 .. T0 + NTT - 1 of the slice ----
+// LDS reads in issue order: bias quads, slope quads, then one A fragment per step S = (tile, k-step), PD steps
+// ahead of its MFMAs through a ring of NB registers.  LDS returns in order, so the wait of step S (at most
+// `outstanding(S)` reads in flight) also covers every quad.
+template <typename T, int KS, int PW1, int T0, int NTT> struct Exp16 {
+    typedef typename vec8<T>::type V8;
+    static constexpr int NS = NTT * KS, PD = 3, NB = PD + 1;
+    static_assert(NTT % 2 == 0 && NS > PD, "tiles are written in pairs (one 16-byte unit per pair)");
+    V8 fr[NB];
+    f32x4 bq[NTT], sl[NTT];
+    f32x4 acc[2];
+    V8 o[2];
+    int w1l;   // LDS address of this lane's W1 image row 16 (g & 1) + m, unit g >> 1; + 32 t PW1 + 32 ks
+    int pl;    // LDS address of the bias quad of channels 4 g ..; + 64 t; slopes 256 further
+
+    template <int S> __device__ __forceinline__ void issue_frag() {
+        LDS_READ16(fr[S % NB], w1l, (T0 + S / KS) * 32 * PW1 + (S % KS) * 32);
+    }
+    template <int I = 0> __device__ __forceinline__ void preamble() {
+        if constexpr (I < NTT) { LDS_READ16(bq[I], pl, 64 * (T0 + I)); preamble<I + 1>(); }
+        else if constexpr (I < 2 * NTT) { LDS_READ16(sl[I - NTT], pl, 256 + 64 * (T0 + I - NTT)); preamble<I + 1>(); }
+        else if constexpr (I < 2 * NTT + PD) { issue_frag<I - 2 * NTT>(); preamble<I + 1>(); }
+    }
+    static constexpr int outstanding(int S) { return cmin(PD, NS - 1 - S); }
+    // lds_px[st]: LDS byte address of this lane's 32-byte share of its pixel slot in subtile st (-1: no pixel)
+    template <int S = 0> __device__ __forceinline__ void run(const V8 (&x)[2][KS], char* lds, const int (&lds_px)[2]) {
+        if constexpr (S < NS) {
+            constexpr int tl = S / KS, ks = S % KS, slot = S % NB;
+            if constexpr (S + PD < NS) issue_frag<S + PD>();
+            if constexpr (ks == 0)
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fr[slot]), "+v"(bq[tl]) : "n"(outstanding(S)));
+            else if constexpr (ks == KS - 1)
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fr[slot]), "+v"(sl[tl]) : "n"(outstanding(S)));
+            else
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fr[slot]) : "n"(outstanding(S)));
+            if constexpr (ks == 0) {
+                acc[0] = mfma16(fr[slot], x[0][0], bq[tl]);
+                acc[1] = mfma16(fr[slot], x[1][0], bq[tl]);
+            } else {
+                acc[0] = mfma16(fr[slot], x[0][ks], acc[0]);
+                acc[1] = mfma16(fr[slot], x[1][ks], acc[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);             // keep each MFMA pair right behind its wait
+            if constexpr (ks == KS - 1) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = acc[st][i];
+                        o[st][4 * (tl & 1) + i] = (T)fmaf(neg_part(v), sl[tl][i], v);   // PReLU: sl = slope - 1
+                    }
+                if constexpr (tl & 1) {
+                    // positions 16 g + 4 t + i of tiles t = T0 + tl - 1, T0 + tl: one 16-byte unit
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+                        if (lds_px[st] >= 0) *reinterpret_cast<V8*>(lds + lds_px[st] + 8 * (T0 + tl - 1)) = o[st];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            run<S + 1>(x, lds, lds_px);
+        }
+    }
+};
+
+// N quads, 64 bytes apart, read from LDS behind one wait
+template <int N> struct QuadLoad {
+    f32x4 q[N];
+    template <int I = 0> __device__ __forceinline__ void issue(int addr) {
+        if constexpr (I < N) { LDS_READ16(q[I], addr, 64 * I); issue<I + 1>(addr); }
+    }
+    // volatile statements keep their order: placed after the wait, whatever uses a quad comes after the wait too
+    template <int I = 0> __device__ __forceinline__ void pin() {
+        if constexpr (I < N) { asm volatile("" : "+v"(q[I])); pin<I + 1>(); }
+    }
+};
+
+template <int C, int CEXP, int H, int TR> constexpr int rblock_lds_bytes() {
+    return (TR + 2) * block_pitch<H, 1>() * 144 + 2 * RbPkg<C>::BYTES;
+}
+
+template <typename T, int C, int CEXP, int H, int TR, int NW>
+__global__ __launch_bounds__(NW * 64, 2)
+void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk) {
+    typedef typename vec8<T>::type V8;
+    typedef typename vec4<T>::type V4;
+    typedef RbPkg<C> PK;
+    constexpr int W = H;
+    constexpr bool WHOLE = (TR == H);                      // the band is the whole image: no halo rows
+    constexpr int RIN = TR + 2;                            // LDS rows: band rows + one row above and below
+    // a tile is RPT whole rows, each padded to POW (a power of two) lanes
+    constexpr int POW = W <= 8 ? 8 : (W <= 16 ? 16 : 32), RPT = 32 / POW;
+    constexpr int MTO = (TR + RPT - 1) / RPT;              // main tiles: expand input == project output
+    constexpr int HT = WHOLE ? 0 : (RPT >= 2 ? 1 : 2);     // halo tiles (rows y0 - 1 and y0 + TR)
+    constexpr int MTI = MTO + HT;
+    constexpr int KS = C / 32, NT16 = C / 16, NCH = CEXP / 64;
+    constexpr int PITCH = block_pitch<H, 1>(), SLOT = 144;
+    constexpr int ES_BYTES = RIN * PITCH * SLOT;
+    constexpr int LDS_BYTES = ES_BYTES + 2 * PK::BYTES;
+    constexpr int MTIW = (MTI + NW - 1) / NW;              // input tiles per wave
+    // with at most NW / 2 input tiles two waves share one and expand two of the slice's four channel tiles each
+    constexpr bool ESPLIT = MTI <= NW / 2;
+    constexpr int MTIP = MTI > 2 ? 4 : (MTI > 1 ? 2 : 1);
+    static_assert(CEXP % 128 == 0 && C % 32 == 0 && H % TR == 0, "shape");
+    static_assert(MTO <= NW, "one output tile per wave");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(LDS_BYTES == rblock_lds_bytes<C, CEXP, H, TR>(), "the launcher's LDS size is this map's");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m16 = lane & 15, g4 = lane >> 4;
+    const int y0 = blockIdx.x * TR;                        // first image row of the band
+    const int npk = nblk * NCH;                            // packages of this launch
+
+    // ---- package staging: piece k (1 KB) is copied by wave k % NW ----------------------------------------------
+    auto stage = [&](int p, int buf) {
+        const char* g = WP + (size_t)p * PK::BYTES + lane * 16;
+        char* l = lds + ES_BYTES + buf * PK::BYTES;
+#pragma unroll
+        for (int j = 0; j < (PK::PIECES + NW - 1) / NW; ++j) {
+            const int k = wave + NW * j;
+            if (k < PK::PIECES)                            // wave-uniform
+                __builtin_amdgcn_global_load_lds((GPTR)(g + k * 1024), (LPTR)(l + k * 1024), 16, 0, 0);
+        }
+    };
+    stage(0, 0);
+
+    // the activation image starts as zeros: border slots and out-of-image rows are never written afterwards
+    for (int i = tid; i < ES_BYTES / 16; i += NW * 64) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- this lane's pixels: tile ti, subtile st -> LDS slot and offset inside an image -------------------------
+    const int we = ESPLIT ? (wave & (MTIP - 1)) : wave, en = ESPLIT ? wave / MTIP : 0;   // wave-uniform
+    int lds_px[MTIW][2];   // LDS byte address of the lane's 32 bytes (positions 16 g ..) of the pixel slot; -1 = no pixel
+    int x_off[MTIW][2];    // element offset of the lane's first channel (4 g) of that pixel inside an image
+#pragma unroll
+    for (int tt = 0; tt < MTIW; ++tt)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int ti = we + NW * tt;
+            int lr, xx, gy;
+            bool ok;
+            const int rr = POW == 32 ? 0 : (POW == 16 ? st : 2 * st + (m16 >> 3));
+            xx = POW == 32 ? 16 * st + m16 : (POW == 16 ? m16 : (m16 & 7));
+            if (ti < MTO) {
+                const int orow = ti * RPT + rr;
+                ok = orow < TR;
+                lr = 1 + orow;
+                gy = y0 + orow;
+            } else {
+                const int which = POW == 32 ? ti - MTO : rr;   // 0: the row above the band, 1: the row below
+                ok = ti < MTI && which < 2;
+                lr = which ? TR + 1 : 0;
+                gy = which ? y0 + TR : y0 - 1;
+            }
+            ok = ok && xx < W && gy >= 0 && gy < H;
+            lds_px[tt][st] = ok ? (lr * PITCH + xx + 1) * SLOT + 32 * g4 : -1;
+            x_off[tt][st] = ok ? (gy * W + xx) * C + 4 * g4 : 4 * g4;
+        }
+
+    // input fragments = B operand of the expand GEMM = the shortcut; element j of k-step ks is channel
+    // 32 ks + 4 g + j (j < 4) or 32 ks + 16 + 4 g + (j - 4)
+    V8 xf[MTIW][2][KS];
+    auto load_x = [&](int img) {
+        const T* Ximg = X + (size_t)img * H * W * C;
+#pragma unroll
+        for (int tt = 0; tt < MTIW; ++tt)
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const V4 lo = *reinterpret_cast<const V4*>(Ximg + x_off[tt][st] + 32 * ks);
+                    const V4 hi = *reinterpret_cast<const V4*>(Ximg + x_off[tt][st] + 32 * ks + 16);
+                    xf[tt][st][ks] = V8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+    };
+
+    // ---- depthwise / project side: wave wt owns output tile wt (its own main input tile) ----------------------
+    const int wt = wave;
+    const bool dw_active = wt < MTO;
+    constexpr int ST1 = POW == 32 ? 16 * SLOT : (16 / POW) * PITCH * SLOT;
+    static_assert(ST1 + 2 * PITCH * SLOT + 96 < 65536, "tap offsets must fit the instruction's offset field");
+    int tb[2];            // LDS byte address of unit (g >> 1) of tap 0 / 1 and of tap 5 / 2 (DwStage::tb)
+    {
+        const int oy = wt * RPT + m16 / POW, ox = m16 % POW;
+        const int h1 = g4 & 1;
+        tb[0] = (oy * PITCH + ox + h1) * SLOT + 16 * (g4 >> 1);                // tap 0 = (0,0) / tap 1 = (0,1)
+        tb[1] = ((oy + 1 - h1) * PITCH + ox + 2) * SLOT + 16 * (g4 >> 1);      // tap 5 = (1,2) / tap 2 = (0,2)
+    }
+    f32x4 pacc[2][NT16];  // tile n of subtile st, register i <-> output channel 16 n + 4 g + i
+
+    auto expand = [&](int buf) {
+        if (we >= MTI || en >= 2) return;                  // wave-uniform
+        const int base = ES_BYTES + buf * PK::BYTES;
+        const int w1l = base + (16 * (g4 & 1) + m16) * PK::PW1 + 16 * (g4 >> 1);
+        const int pl = base + PK::OFF_B1 + 16 * g4;
+#pragma unroll
+        for (int tt = 0; tt < MTIW; ++tt) {
+            if (we + NW * tt >= MTI) break;                // wave-uniform
+            if constexpr (ESPLIT) {
+                if (en == 0) { Exp16<T, KS, PK::PW1, 0, 2> ex; ex.w1l = w1l; ex.pl = pl; ex.preamble(); ex.run(xf[tt], lds, lds_px[tt]); }
+                else         { Exp16<T, KS, PK::PW1, 2, 2> ex; ex.w1l = w1l; ex.pl = pl; ex.preamble(); ex.run(xf[tt], lds, lds_px[tt]); }
+            } else {
+                Exp16<T, KS, PK::PW1, 0, 4> ex; ex.w1l = w1l; ex.pl = pl; ex.preamble(); ex.run(xf[tt], lds, lds_px[tt]);
+            }
+        }
+    };
+    auto dwproject = [&](int buf) {
+        if (!dw_active) return;                            // wave-uniform
+        const int base = ES_BYTES + buf * PK::BYTES;
+        DwStage<T, 64, NT16, PK::PW3, ST1, PITCH * SLOT, 4> dw;
+        dw.tb[0] = tb[0];
+        dw.tb[1] = tb[1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            dw.msk[i] = ((m16 >> 3) == (g4 >> 1) && ((m16 & 7) >> 1) == i) ? ((m16 & 1) ? 0xFFFF0000u : 0x0000FFFFu) : 0u;
+        dw.w2l[0] = base + PK::OFF_W2 + (g4 & 1) * PK::PW2 + m16 * 2;
+        dw.w2l[1] = base + PK::OFF_W2 + (5 + 4 * (g4 & 1)) * PK::PW2 + m16 * 2;
+        dw.pb = base + PK::OFF_B2 + 16 * g4;
+        dw.w3l = base + PK::OFF_W3 + (16 * (g4 & 1) + m16) * PK::PW3 + 16 * (g4 >> 1);
+        dw.preamble();
+        dw.run(pacc);
+    };
+
+    // A workgroup keeps its band and walks over images blockIdx.y, blockIdx.y + gridDim.y, ...
+    for (int img = blockIdx.y; img < B; img += gridDim.y) {
+        const bool has_next = img + (int)gridDim.y < B;
+        load_x(img);
+        if (img == (int)blockIdx.y) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // package 0 (later images: waited for at the previous image's end)
+            __syncthreads();                                   // ... and the zeroed image
+        }
+        int p = 0;                                             // package of the current slice
+#pragma unroll 1
+        for (int b = 0; b < nblk; ++b) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int n = 0; n < NT16; ++n) pacc[st][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int c = 0; c < NCH; ++c, ++p) {
+                const int buf = c & 1;                         // NCH is even: the parity carries across blocks and images
+                // next package into the other buffer (last read before the previous barrier)
+                if (p + 1 < npk) stage(p + 1, buf ^ 1);
+                else if (has_next) stage(0, buf ^ 1);
+                expand(buf);
+                // the image of this slice is complete.  Not __syncthreads(): its fence would also wait for the LDS-DMA in flight
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                dwproject(buf);
+                if (c == NCH - 1 && dw_active) {
+                    // ---- epilogue in registers: x <- round((acc + x) + b3), channel for channel what the lane holds ----
+                    QuadLoad<NT16> bq3;                        // b3 of channels 16 n + 4 g ..
+                    bq3.issue(ES_BYTES + buf * PK::BYTES + PK::OFF_B3 + 16 * g4);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    bq3.pin();
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int n = 2 * ks + (j >> 2), i = j & 3;
+                                const float v = pacc[st][n][i] + (float)xf[0][st][ks][j];
+                                xf[0][st][ks][j] = (T)(v + bq3.q[n][i]);
+                            }
+                    if (b == nblk - 1) {
+                        T* Oimg = O + (size_t)img * H * W * C;
+#pragma unroll
+                        for (int st = 0; st < 2; ++st)
+                            if (lds_px[0][st] >= 0) {
+#pragma unroll
+                                for (int ks = 0; ks < KS; ++ks) {
+                                    const V8 v = xf[0][st][ks];
+                                    *reinterpret_cast<V4*>(Oimg + x_off[0][st] + 32 * ks) = V4{v[0], v[1], v[2], v[3]};
+                                    *reinterpret_cast<V4*>(Oimg + x_off[0][st] + 32 * ks + 16) = V4{v[4], v[5], v[6], v[7]};
+                                }
+                            }
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                               // image free, next package visible
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int rb_resident_workgroups(const void* kernel, int threads, int lds_bytes) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, (size_t)lds_bytes) != hipSuccess || per_cu <= 0)
+        per_cu = 1;
+    return cus * per_cu;
+}
+
+static int rb_compute_units() {
+    static std::atomic<int> cus_of[64];
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev < 64 && (cus = cus_of[dev].load(std::memory_order_relaxed)) > 0) return cus;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (dev < 64) cus_of[dev].store(cus, std::memory_order_relaxed);
+    return cus;
+}
+
+template <typename T, int C, int CEXP, int H, int TR, int NW>
+static int launch_rblock_cfg(const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s) {
+    constexpr int bands = H / TR;
+    constexpr int lds = rblock_lds_bytes<C, CEXP, H, TR>();
+    FRA_REQUIRE(nblk == 1 || TR == H, FRA_ERR_ARG, "rblock: %d blocks per launch need whole-image workgroups", nblk);
+    auto kern = rblock_kernel<T, C, CEXP, H, TR, NW>;
+    static std::atomic<uint64_t> lds_set;      // per instantiation: devices whose LDS limit is raised
+    static std::atomic<int> slots_of[64];      // resident workgroups per band, per device (0 = not asked yet)
+    int dev = 0;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set, &dev)) return rc;
+    int slots = dev < 64 ? slots_of[dev].load(std::memory_order_relaxed) : 0;
+    if (slots == 0) {
+        slots = rb_resident_workgroups(reinterpret_cast<const void*>(kern), NW * 64, lds) / bands;
+        if (slots < 1) slots = 1;
+        if (dev < 64) slots_of[dev].store(slots, std::memory_order_relaxed);
+    }
+    // one workgroup per band and resident slot, each walking over its images in equal shares
+    const int per = (B + slots - 1) / slots;
+    const int groups = (B + per - 1) / per;
+    hipLaunchKernelGGL(kern, dim3(bands, groups), dim3(NW * 64), lds, s, (const T*)x, (const char*)wp, (T*)out, B, nblk);
+    FRA_HIP(hipGetLastError());
+    return FRA_OK;
+}
+
+// conv_4 (128 -> 256 -> 128 on 14 x 14): bands of 2 rows (7 workgroups per image) while those fit the chip in
+// one go, bands of 7 rows (2 per image) while those do, whole images beyond
+template <typename T>
+static int launch_rblock_t(int c, int cexp, int h, const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s) {
+    const int cus = rb_compute_units();
+    if (c == 128 && cexp == 256 && h == 14) {
+        if (nblk > 1) return launch_rblock_cfg<T, 128, 256, 14, 14, 8>(x, wp, nblk, out, B, s);
+        if ((int64_t)B * 7 <= cus) return launch_rblock_cfg<T, 128, 256, 14, 2, 8>(x, wp, 1, out, B, s);
+        if ((int64_t)B * 2 <= cus) return launch_rblock_cfg<T, 128, 256, 14, 7, 8>(x, wp, 1, out, B, s);
+        return launch_rblock_cfg<T, 128, 256, 14, 14, 8>(x, wp, 1, out, B, s);
+    }
+    FRA_REQUIRE(false, FRA_ERR_ARG, "rblock: no kernel for c=%d cexp=%d h=%d", c, cexp, h);
+    return FRA_ERR_ARG;
+}
+
+bool rblock_chain_pays(int c, int cexp, int h, int B) {
+    // whole-image workgroups: worth it once they fill more of the chip than two-band workgroups would
+    return c == 128 && cexp == 256 && h == 14 && (int64_t)B * 2 > rb_compute_units();
+}
+
+int launch_rblock(int dt, int c, int cexp, int h, const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s) {
+    FRA_REQUIRE(x && wp && out, FRA_ERR_ARG, "rblock: null pointer");
+    FRA_REQUIRE(B > 0 && B <= 65535, FRA_ERR_ARG, "rblock: batch %d not in [1,65535]", B);
+    FRA_REQUIRE(nblk >= 1 && nblk <= 64, FRA_ERR_ARG, "rblock: %d blocks", nblk);
+    FRA_REQUIRE((((uintptr_t)wp) & 15) == 0, FRA_ERR_ARG, "rblock: packages must be 16-byte aligned");
+    if (dt == ACT_F16) return launch_rblock_t<f16>(c, cexp, h, x, wp, nblk, out, B, s);
+    if (dt == ACT_BF16) return launch_rblock_t<bf16>(c, cexp, h, x, wp, nblk, out, B, s);
+    FRA_REQUIRE(false, FRA_ERR_ARG, "rblock: unsupported activation dtype %d", dt);
+    return FRA_ERR_ARG;
+}
+
+// ---- host side: folded weights -> packages --------------------------------------------------------------------
+size_t rblock_package_bytes(int c, int cexp) {
+    if (cexp % 128 != 0) return 0;
+    if (c == 128) return (size_t)(cexp / 64) * RbPkg<128>::BYTES;
+    if (c == 64) return (size_t)(cexp / 64) * RbPkg<64>::BYTES;
+    return 0;
+}
+
+static uint16_t rb_to16(int dt, float f) {
+    if (dt == ACT_BF16) {
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+        return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+    _Float16 hv = (_Float16)f;
+    uint16_t b;
+    memcpy(&b, &hv, 2);
+    return b;
+}
+
+template <int C>
+static void pack_rblock_c(int dt, int cexp, const float* w1, const float* b1, const float* s1, const float* w2,
+                          const float* b2, const float* s2, const float* w3, const float* b3, unsigned char* out) {
+    typedef RbPkg<C> PK;
+    const int nch = cexp / 64;
+    memset(out, 0, (size_t)nch * PK::BYTES);
+    for (int c = 0; c < nch; ++c) {
+        unsigned char* pk = out + (size_t)c * PK::BYTES;
+        for (int el = 0; el < 64; ++el) {
+            const int e = 64 * c + el, t = el >> 4, m = el & 15, pos = rb_pos(el);
+            for (int par = 0; par < 2; ++par) {
+                uint16_t* row = reinterpret_cast<uint16_t*>(pk + (size_t)(32 * t + 16 * par + m) * PK::PW1);
+                for (int ks = 0; ks < C / 32; ++ks)
+                    for (int gh = 0; gh < 2; ++gh)
+                        for (int j = 0; j < 8; ++j)
+                            row[(2 * ks + gh) * 8 + j] = rb_to16(dt, w1[(size_t)e * C + rb_in_channel(ks, 2 * gh + par, j)]);
+            }
+            reinterpret_cast<float*>(pk + PK::OFF_B1)[el] = b1[e];
+            reinterpret_cast<float*>(pk + PK::OFF_S1)[el] = s1[e] - 1.0f;
+            reinterpret_cast<float*>(pk + PK::OFF_B2)[pos] = b2[e];
+            reinterpret_cast<float*>(pk + PK::OFF_S2)[pos] = s2[e] - 1.0f;
+            for (int r = 0; r < 10; ++r) {                 // rows 0..8 the taps, row 9 tap 2 again, rows 10..12 stay zero
+                const int tap = r == 9 ? 2 : r;
+                reinterpret_cast<uint16_t*>(pk + PK::OFF_W2 + r * PK::PW2)[pos] = rb_to16(dt, w2[(size_t)e * 9 + tap]);
+            }
+            const int P = (pos >> 5) & 1, hi = (pos >> 4) & 1, g = (pos >> 2) & 3, i = pos & 3;
+            for (int co = 0; co < C; ++co) {
+                uint16_t* row = reinterpret_cast<uint16_t*>(pk + PK::OFF_W3 + (size_t)(32 * (co >> 4) + 16 * (g & 1) + (co & 15)) * PK::PW3);
+                row[(2 * P + (g >> 1)) * 8 + 4 * hi + i] = rb_to16(dt, w3[(size_t)co * cexp + e]);
+            }
+        }
+        for (int co = 0; co < C; ++co) reinterpret_cast<float*>(pk + PK::OFF_B3)[co] = b3[co];
+    }
+}
+
+int pack_rblock(int dt, int c, int cexp, const float* w1, const float* b1, const float* s1, const float* w2,
+                const float* b2, const float* s2, const float* w3, const float* b3, void* out) {
+    FRA_REQUIRE(w1 && b1 && s1 && w2 && b2 && s2 && w3 && b3 && out, FRA_ERR_ARG, "pack_rblock: null pointer");
+    FRA_REQUIRE(dt == ACT_F16 || dt == ACT_BF16, FRA_ERR_ARG, "pack_rblock: dtype %d", dt);
+    FRA_REQUIRE(rblock_package_bytes(c, cexp) > 0, FRA_ERR_ARG, "pack_rblock: unsupported widths c=%d cexp=%d", c, cexp);
+    if (c == 128) pack_rblock_c<128>(dt, cexp, w1, b1, s1, w2, b2, s2, w3, b3, static_cast<unsigned char*>(out));
+    else pack_rblock_c<64>(dt, cexp, w1, b1, s1, w2, b2, s2, w3, b3, static_cast<unsigned char*>(out));
+    return FRA_OK;
+}
+
+}  // namespace fra

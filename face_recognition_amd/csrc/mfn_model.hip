@@ -36,6 +36,12 @@ struct Op {
     bool residual = false;
     size_t blk_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // w1, b1p, s1p, w2p, b2p, s2p, w3p, b3
     BlockParams bp = {};
+    // OP_BLOCK run by the register-resident residual kernel (rblock): its weight packages in the arena; the packages
+    // of consecutive ops of one chain are contiguous.  chain_pos = index inside the chain, chain_len = its length
+    bool rblock = false;
+    size_t rb_off = 0;
+    const void* rb = nullptr;
+    int chain_pos = 0, chain_len = 1;
     // OP_STEMDW only
     size_t sd_off[6] = {0, 0, 0, 0, 0, 0};          // wa, b1, s1, w2, b2, s2
     StemDwParams sp = {};
@@ -55,6 +61,7 @@ struct mfn_handle {
     int chunk = 0;
     bool loaded = false;
     bool fused = true;                 // run inverted-residual blocks as one kernel each
+    bool chain = true;                 // ... and runs of identical residual blocks as one launch where that pays
     std::vector<fra::Op> ops_plain;    // one kernel per conv
     std::vector<fra::Op> ops_fused;    // one kernel per block
     std::vector<fra::Op>& ops() { return fused ? ops_fused : ops_plain; }
@@ -124,6 +131,7 @@ static void build_ops(mfn_handle* h, bool fused) {
         add(OP_DW, "conv2_dw", BUF_P0, BUF_P1, NO_RESID, 64, 64, 56, 56, 1, true);
     }
     int cur = BUF_P1;
+    int chain_i = 0, chain_n = 1;   // position / length of the run of identical residual blocks being added
     auto block = [&](const std::string& p, int cin, int cexp, int cout, int stride, bool res, int hin) {
         const int hout = (hin + 2 - 3) / stride + 1;
         const int other = cur == BUF_P0 ? BUF_P1 : BUF_P0;
@@ -136,6 +144,11 @@ static void build_ops(mfn_handle* h, bool fused) {
             o.flops = 2.0 * (pin * cin * cexp + pout * cexp * 9 + pout * cexp * cout);
             o.bytes = (pin * cin + pout * cout) * es;    // the shortcut re-reads the input tile: no extra traffic
             o.wbytes = ((double)cin * cexp + 9.0 * cexp + (double)cexp * cout) * es;
+            if (res && stride == 1 && cin == 128 && hin == 14 && rblock_package_bytes(cin, cexp) > 0) {   // conv_4.*
+                o.rblock = true;
+                o.chain_pos = chain_i;
+                o.chain_len = chain_n;
+            }
             cur = other;
             return;
         }
@@ -148,7 +161,9 @@ static void build_ops(mfn_handle* h, bool fused) {
     block("conv_23", 64, 128, 64, 2, false, 56);
     for (int i = 0; i < 4; ++i) block("conv_3.model." + std::to_string(i), 64, 128, 64, 1, true, 28);
     block("conv_34", 64, 256, 128, 2, false, 28);
-    for (int i = 0; i < 6; ++i) block("conv_4.model." + std::to_string(i), 128, 256, 128, 1, true, 14);
+    chain_n = 6;
+    for (chain_i = 0; chain_i < 6; ++chain_i) block("conv_4.model." + std::to_string(chain_i), 128, 256, 128, 1, true, 14);
+    chain_i = 0; chain_n = 1;
     block("conv_45", 128, 512, 128, 2, false, 14);
     for (int i = 0; i < 2; ++i) block("conv_5.model." + std::to_string(i), 128, 256, 128, 1, true, 7);
     // face_model.py:88-92
@@ -239,6 +254,12 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
     for (Op& o : h->ops_fused) all.push_back(&o);
     for (Op* op : all) {
         Op& o = *op;
+        if (o.kind == OP_BLOCK && o.rblock) {
+            // packages are whole KB, so the ops of a chain stay contiguous (the chain kernel streams across them)
+            o.rb_off = off;
+            off += rblock_package_bytes(o.cin, o.cexp);
+            continue;
+        }
         if (o.kind == OP_BLOCK) {
             const size_t sz[8] = {(size_t)o.cexp * o.cin * 2, (size_t)o.cexp * 4, (size_t)o.cexp * 4, 9 * (size_t)o.cexp * 2,
                                   (size_t)o.cexp * 4,         (size_t)o.cexp * 4, (size_t)o.cout * o.cexp * 2, (size_t)o.cout * 4};
@@ -326,6 +347,35 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
                 for (int t = 0; t < 49; ++t) w7[(size_t)t * C + c] = to16(dt, (float)(w[(size_t)c * 49 + t] * scale[c]));
                 b7[c] = (float)shift[c];
             }
+            continue;
+        }
+        if (o.kind == OP_BLOCK && o.rblock) {
+            const int CE = o.cexp, CI = o.cin;
+            const float *a1, *a2, *w2, *w3;
+            std::vector<double> sc2, sh2, sc3, sh3;
+            if ((rc = fetch(m, o.name + ".conv.conv.weight", (int64_t)CE * CI, &w))) return rc;
+            if ((rc = bn_fold(m, o.name + ".conv.bn", CE, scale, shift))) return rc;
+            if ((rc = fetch(m, o.name + ".conv.prelu.weight", CE, &a1))) return rc;
+            if ((rc = fetch(m, o.name + ".conv_dw.conv.weight", (int64_t)CE * 9, &w2))) return rc;
+            if ((rc = bn_fold(m, o.name + ".conv_dw.bn", CE, sc2, sh2))) return rc;
+            if ((rc = fetch(m, o.name + ".conv_dw.prelu.weight", CE, &a2))) return rc;
+            if ((rc = fetch(m, o.name + ".project.conv.weight", (int64_t)C * CE, &w3))) return rc;
+            if ((rc = bn_fold(m, o.name + ".project.bn", C, sc3, sh3))) return rc;
+            // the same folded values (rounded to float the same way) as the one-kernel-per-block layout below
+            std::vector<float> fw1((size_t)CE * CI), fb1(CE), fw2((size_t)CE * 9), fb2(CE), fw3((size_t)C * CE), fb3(C);
+            for (int e = 0; e < CE; ++e) {
+                for (int k = 0; k < CI; ++k) fw1[(size_t)e * CI + k] = (float)(w[(size_t)e * CI + k] * scale[e]);
+                fb1[e] = (float)shift[e];
+                for (int t = 0; t < 9; ++t) fw2[(size_t)e * 9 + t] = (float)(w2[(size_t)e * 9 + t] * sc2[e]);
+                fb2[e] = (float)sh2[e];
+            }
+            for (int n = 0; n < C; ++n) {
+                for (int e = 0; e < CE; ++e) fw3[(size_t)n * CE + e] = (float)(w3[(size_t)n * CE + e] * sc3[n]);
+                fb3[n] = (float)sh3[n];
+            }
+            if ((rc = pack_rblock(dt, CI, CE, fw1.data(), fb1.data(), a1, fw2.data(), fb2.data(), a2, fw3.data(), fb3.data(),
+                                  host.data() + o.rb_off)))
+                return rc;
             continue;
         }
         if (o.kind == OP_BLOCK) {
@@ -424,6 +474,10 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
             for (int i = 0; i < 5; ++i) o.tl[i] = base + o.tl_off[i];
             continue;
         }
+        if (o.kind == OP_BLOCK && o.rblock) {
+            o.rb = base + o.rb_off;
+            continue;
+        }
         if (o.kind == OP_BLOCK) {
             BlockParams& b = o.bp;
             b.cin = o.cin; b.cexp = o.cexp; b.cout = o.cout; b.h = o.hin; b.stride = o.stride; b.residual = o.residual;
@@ -467,8 +521,19 @@ static WsPlan plan_ws(int b, int E, bool tta) {
 static int slice_size(const mfn_handle* h, int B) { return (h->chunk > 0 && h->chunk < B) ? h->chunk : B; }
 
 // b = images in the activation buffers; x holds n_src source crops (b == n_src, or 2 n_src with mirrored copies)
+// Blocks that op i's launch covers in a batch of b images when at most `limit` ops may run: a run of register-resident
+// residual blocks goes out as one launch where whole-image workgroups pay.
+static int ops_in_launch(const mfn_handle* h, int i, int b, int limit) {
+    const Op& o = h->ops()[i];
+    if (o.kind != OP_BLOCK || !o.rblock || o.chain_len - o.chain_pos < 2 || !h->chain) return 1;
+    if (!rblock_chain_pays(o.cin, o.cexp, o.hin, b)) return 1;
+    const int n = o.chain_len - o.chain_pos;
+    return n < limit ? n : limit;
+}
+
+// `nblk` > 1: op o and the nblk - 1 ops after it as one launch, written where the last of them writes
 static int run_op(const mfn_handle* h, const Op& o, const void* x, int x_is_u8, int n_src, float* out, char* ws,
-                  const WsPlan& p, int b, hipStream_t s) {
+                  const WsPlan& p, int b, hipStream_t s, int nblk = 1) {
     auto buf = [&](int id) -> void* { return ws + p.off[id]; };
     switch (o.kind) {
         case OP_STEM:
@@ -484,6 +549,8 @@ static int run_op(const mfn_handle* h, const Op& o, const void* x, int x_is_u8, 
         case OP_LINEAR:
             return launch_linear_l2norm(h->dt, buf(o.in), o.w, o.bias, out, b, o.cin, o.cout, s);
         case OP_BLOCK:
+            if (o.rblock)   // blocks ping-pong between two buffers: an even count ends in the buffer it started from
+                return launch_rblock(h->dt, o.cin, o.cexp, o.hin, buf(o.in), o.rb, nblk, buf((nblk & 1) ? o.out : o.in), b, s);
             return launch_block(h->dt, o.bp, buf(o.in), buf(o.out), b, s);
         case OP_STEMDW:
             return launch_stemdw(h->dt, o.sp, x, x_is_u8, n_src, buf(o.out), b, s);
@@ -535,14 +602,17 @@ static int forward(mfn_handle* h, const void* x, int x_is_u8, int B, bool tta, f
         float* os = out + (size_t)b0 * h->E;
         float* emb = tta ? reinterpret_cast<float*>(static_cast<char*>(ws) + p.emb) : os;
         if (op_ms) FRA_HIP(hipEventRecord(ev[0], s));
-        for (int i = 0; i < nops; ++i) {
-            rc = run_op(h, h->ops()[i], xs, x_is_u8, b, emb, static_cast<char*>(ws), p, nb, s);
+        for (int i = 0; i < nops;) {
+            const int n = ops_in_launch(h, i, nb, nops - i);
+            rc = run_op(h, h->ops()[i], xs, x_is_u8, b, emb, static_cast<char*>(ws), p, nb, s, n);
             if (rc) return rc;
-            if (i == nops - 1 && tta) {   // l2_norm(emb + emb_mirror): facebank.py:62
+            if (i + n == nops && tta) {   // l2_norm(emb + emb_mirror): facebank.py:62
                 rc = launch_add_l2norm(emb, emb + (size_t)b * h->E, os, b, h->E, s);
                 if (rc) return rc;
             }
-            if (op_ms) FRA_HIP(hipEventRecord(ev[i + 1], s));
+            // a launch that covers several ops is booked on its first op; the others read 0 ms
+            if (op_ms) for (int j = 1; j <= n; ++j) FRA_HIP(hipEventRecord(ev[i + j], s));
+            i += n;
         }
         if (op_ms) {
             FRA_HIP(hipEventSynchronize(ev[nops]));
@@ -612,6 +682,24 @@ int mfn_set_fused(mfn_handle* h, int fused) {
     return FRA_OK;
 }
 
+int mfn_set_chain(mfn_handle* h, int chain) {
+    FRA_REQUIRE(h != nullptr, FRA_ERR_ARG, "mfn_set_chain: null handle");
+    h->chain = chain != 0;
+    return FRA_OK;
+}
+
+int mfn_launch_plan(const mfn_handle* h, int B, int* first_op, int n_ops) {
+    FRA_REQUIRE(h && first_op && B > 0, FRA_ERR_ARG, "mfn_launch_plan: bad argument");
+    const int nops = (int)h->ops().size();
+    FRA_REQUIRE(n_ops >= nops, FRA_ERR_ARG, "mfn_launch_plan: room for %d ops, model has %d", n_ops, nops);
+    for (int i = 0; i < nops;) {
+        const int n = ops_in_launch(h, i, B, nops - i);
+        for (int j = 0; j < n; ++j) first_op[i + j] = i;
+        i += n;
+    }
+    return FRA_OK;
+}
+
 int mfn_forward(mfn_handle* h, const float* x, int B, float* out, void* ws, size_t ws_bytes, fra_stream stream) {
     return forward(h, x, 0, B, false, out, ws, ws_bytes, (hipStream_t)stream, nullptr, 0);
 }
@@ -655,9 +743,11 @@ int mfn_debug_prefix(mfn_handle* h, const float* x, int B, int n_ops, float* out
     FRA_REQUIRE(slice_size(h, B) == B, FRA_ERR_STATE, "mfn_debug_prefix: batch chunking must be off");
     const WsPlan p = plan_ws(B, h->E, false);
     hipStream_t s = (hipStream_t)stream;
-    for (int i = 0; i < n_ops; ++i) {
-        rc = run_op(h, h->ops()[i], x, 0, B, nullptr, static_cast<char*>(ws), p, B, s);
+    for (int i = 0; i < n_ops;) {
+        const int n = ops_in_launch(h, i, B, n_ops - i);
+        rc = run_op(h, h->ops()[i], x, 0, B, nullptr, static_cast<char*>(ws), p, B, s, n);
         if (rc) return rc;
+        i += n;
     }
     const Op& o = h->ops()[n_ops - 1];
     const int64_t per = (int64_t)o.hout * o.hout * o.cout;
@@ -698,6 +788,15 @@ int mfn_op_block(int dtype, int cin, int cexp, int cout, int h, int stride, int 
     p.cin = cin; p.cexp = cexp; p.cout = cout; p.h = h; p.stride = stride; p.residual = residual;
     p.w1 = w1; p.b1p = b1p; p.s1p = s1p; p.w2p = w2p; p.b2p = b2p; p.s2p = s2p; p.w3p = w3p; p.b3 = b3;
     return launch_block(dtype, p, x, out, B, (hipStream_t)stream);
+}
+int64_t mfn_rblock_package_bytes(int c, int cexp) { return (int64_t)rblock_package_bytes(c, cexp); }
+int mfn_pack_rblock(int dtype, int c, int cexp, const float* w1, const float* b1, const float* s1, const float* w2,
+                    const float* b2, const float* s2, const float* w3, const float* b3, void* packages_host) {
+    return pack_rblock(dtype, c, cexp, w1, b1, s1, w2, b2, s2, w3, b3, packages_host);
+}
+int mfn_op_rblock(int dtype, int c, int cexp, int h, const void* x, const void* packages, int nblk, void* out, int B,
+                  fra_stream stream) {
+    return launch_rblock(dtype, c, cexp, h, x, packages, nblk, out, B, (hipStream_t)stream);
 }
 int mfn_op_gdconv7(int dtype, const void* in, const void* w, const float* bias, void* out, int B, int C,
                    fra_stream stream) {

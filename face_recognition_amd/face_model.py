@@ -116,6 +116,7 @@ class MobileFaceNet(nn.Module):
         self._workspace: Optional[torch.Tensor] = None
         self._batch_chunk = 0
         self._fused = True
+        self._chain = True
 
     # ---- weight life cycle --------------------------------------------------------------------
     def _apply(self, fn, *args, **kwargs):
@@ -149,6 +150,23 @@ class MobileFaceNet(nn.Module):
         if self._handle is not None:
             _lib.check(_lib.load().mfn_set_fused(self._handle, int(self._fused)), "mfn_set_fused")
 
+    def set_chain(self, chain: bool) -> None:
+        """True (default): runs of identical residual blocks (conv_4) go out as one launch for large batches;
+        False: one launch per block.  Results are bit-identical either way."""
+        self._chain = bool(chain)
+        if self._handle is not None:
+            _lib.check(_lib.load().mfn_set_chain(self._handle, int(self._chain)), "mfn_set_chain")
+
+    def launch_plan(self, batch: int):
+        """For every op of op_table(): index of the op whose launch covers it in a batch of ``batch`` crops."""
+        lib = _lib.load()
+        if self._handle is None:
+            raise RuntimeError("launch_plan: run a forward first")
+        n = lib.mfn_op_count(self._handle)
+        first = (C.c_int * n)()
+        _lib.check(lib.mfn_launch_plan(self._handle, int(batch), first, n), "mfn_launch_plan")
+        return list(first)
+
     def _ensure_handle(self, device: torch.device):
         lib = _lib.load()
         if self._handle is not None and self._handle_device != device:
@@ -162,6 +180,7 @@ class MobileFaceNet(nn.Module):
             self._handle, self._handle_device, self._dirty = h.value, device, True
             _lib.check(lib.mfn_set_batch_chunk(self._handle, self._batch_chunk), "mfn_set_batch_chunk")
             _lib.check(lib.mfn_set_fused(self._handle, int(self._fused)), "mfn_set_fused")
+            _lib.check(lib.mfn_set_chain(self._handle, int(getattr(self, "_chain", True))), "mfn_set_chain")
         if self._dirty:
             sd = self.state_dict()
             keep, descs = [], (_lib.TensorDesc * len(sd))()

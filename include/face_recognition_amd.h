@@ -70,6 +70,14 @@ int mfn_set_batch_chunk(mfn_handle* h, int images);
  * as one kernel; 0: one kernel per conv.  Changes mfn_op_count / mfn_op_info / mfn_debug_prefix. */
 int mfn_set_fused(mfn_handle* h, int fused);
 
+/* chain != 0 (the default): a run of identical residual blocks (conv_4.model.0-5, face_model.py:85) goes out as
+ * ONE launch that keeps the activation in registers between blocks, for batches where whole-image workgroups
+ * fill the chip; 0: one launch per block.  Same results bit for bit either way. */
+int mfn_set_chain(mfn_handle* h, int chain);
+/* first_op[i] (host, n_ops >= mfn_op_count entries) = the op whose launch covers op i in a batch of B images:
+ * i itself, or the first block of the chain i runs in.  mfn_forward_timed books a chain's time on that op. */
+int mfn_launch_plan(const mfn_handle* h, int B, int* first_op, int n_ops);
+
 /* x: dev f32 [B,3,112,112] NCHW (BGR, [-1,1]) -> out: dev f32 [B,embedding_size], rows unit L2 norm.
  * Replaces MobileFaceNet.forward: face_model.py:103-129. */
 int mfn_forward(mfn_handle* h, const float* x_nchw, int B, float* out, void* workspace, size_t workspace_bytes,
@@ -126,6 +134,17 @@ int mfn_op_pw(int dtype, const void* in, const void* wNxK, const float* bias, co
 int mfn_op_block(int dtype, int cin, int cexp, int cout, int h, int stride, int residual, const void* x,
                  const void* w1, const float* b1p, const float* s1p, const void* w2p, const float* b2p,
                  const float* s2p, const void* w3p, const float* b3, void* out, int B, fra_stream stream);
+/* Residual blocks (stride 1, c -> cexp -> c, + x; face_model.py:55-75) whose weights travel as per-slice packages
+ * in the kernel's LDS layout.  mfn_pack_rblock builds the packages of ONE block on the host from BN-folded
+ * weights in natural order: w1 [cexp][c], w2 [cexp][9] (tap = 3 ky + kx), w3 [c][cexp], biases, PReLU slopes
+ * s1 / s2 [cexp]; out must hold mfn_rblock_package_bytes(c, cexp) bytes (0 = unsupported widths).
+ * mfn_op_rblock runs nblk blocks whose packages lie back to back at `packages` (dev) on x -> out, both
+ * T NHWC [B][h][h][c]; out may be x.  nblk > 1 keeps the activation in registers between blocks. */
+int64_t mfn_rblock_package_bytes(int c, int cexp);
+int mfn_pack_rblock(int dtype, int c, int cexp, const float* w1, const float* b1, const float* s1, const float* w2,
+                    const float* b2, const float* s2, const float* w3, const float* b3, void* packages_host);
+int mfn_op_rblock(int dtype, int c, int cexp, int h, const void* x, const void* packages, int nblk, void* out, int B,
+                  fra_stream stream);
 int mfn_op_gdconv7(int dtype, const void* in, const void* w49xC, const float* bias, void* out, int B, int C,
                    fra_stream stream);
 /* conv_6_sep + conv_6_dw in one kernel (face_model.py:88-89): x [B][49][128] NHWC, w6 [512][128] (BN folded),

@@ -121,6 +121,59 @@ def _w3_image(w3pos, cout):
     return out
 
 
+def _rblock_packages(lib, code, c, cexp, w1, b1, s1, w2, b2, s2, w3, b3):
+    """Host packer of the library: folded weights in natural order -> the per-slice packages mfn_op_rblock streams."""
+    n = lib.mfn_rblock_package_bytes(c, cexp)
+    assert n > 0
+    pk = torch.zeros(n, dtype=torch.uint8)
+    arrs = [t.contiguous().float() for t in (w1, b1, s1, w2.reshape(cexp, 9), b2, s2, w3, b3)]
+    _lib.check(lib.mfn_pack_rblock(code, c, cexp, *[a.data_ptr() for a in arrs], pk.data_ptr()), "pack_rblock")
+    return pk
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("B", [2, 37, 129, 300])
+def test_rblock_chain(device, dt, B):
+    """Three residual blocks (128 -> 256 -> 128 on 14 x 14) back to back: one launch with the activation kept in
+    registers == three launches bit for bit, for every band configuration the batch size selects (2-row bands,
+    7-row bands, whole images), and both match the torch convs on 16-bit-rounded operands."""
+    tdt, code, rel = DT[dt]
+    lib = _lib.load()
+    c, cexp, H, nblk = 128, 256, 14, 3
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((B, c, H, H), generator=g).to(tdt).float()
+    pks, y = [], x
+    for _ in range(nblk):
+        w1 = (torch.randn((cexp, c), generator=g) / np.sqrt(c) * 1.3).to(tdt).float()
+        b1, s1 = torch.randn(cexp, generator=g) * 0.2, torch.rand(cexp, generator=g) * 0.3 + 0.1
+        w2 = (torch.randn((cexp, 1, 3, 3), generator=g) * 0.4).to(tdt).float()
+        b2, s2 = torch.randn(cexp, generator=g) * 0.2, torch.rand(cexp, generator=g) * 0.3 + 0.1
+        w3 = (torch.randn((c, cexp), generator=g) / np.sqrt(cexp) * 0.6).to(tdt).float()
+        b3 = torch.randn(c, generator=g) * 0.2
+        pks.append(_rblock_packages(lib, code, c, cexp, w1, b1, s1, w2, b2, s2, w3, b3))
+        e = F.prelu(F.conv2d(y, w1[:, :, None, None], b1), s1).to(tdt).float()
+        d = F.prelu(F.conv2d(e, w2, b2, 1, 1, 1, cexp), s2).to(tdt).float()
+        y = (F.conv2d(d, w3[:, :, None, None], b3) + y).to(tdt).float()
+    ref = y.permute(0, 2, 3, 1).contiguous()
+    pk = torch.cat(pks).to(device)
+    per = pks[0].numel()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(tdt).to(device)
+    # one launch per block (band configuration by batch size)
+    cur = xd
+    for i in range(nblk):
+        nxt = torch.full_like(xd, float("nan"))
+        _lib.check(lib.mfn_op_rblock(code, c, cexp, H, cur.data_ptr(), pk.data_ptr() + i * per, 1, nxt.data_ptr(), B,
+                                     stream(device)), "rblock")
+        cur = nxt
+    # one launch for all three, written over its own input
+    chained = xd.clone()
+    _lib.check(lib.mfn_op_rblock(code, c, cexp, H, chained.data_ptr(), pk.data_ptr(), nblk, chained.data_ptr(), B,
+                                 stream(device)), "rblock chain")
+    torch.cuda.synchronize()
+    assert torch.equal(cur, chained)
+    close(chained, ref, 6 * rel, f"rblock chain B={B}")
+
+
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("many", [False, True])
 @pytest.mark.parametrize("cin,cexp,cout,H,stride,res,B", [(64, 128, 64, 56, 2, False, 2), (64, 128, 64, 28, 1, True, 3),
@@ -160,6 +213,14 @@ def test_fused_block(device, dt, cin, cexp, cout, H, stride, res, B, many):
     w3d, b3d = dev(_w3_image(w3[:, inv], cout).to(tdt)), dev(b3)
     Ho = H // stride
     out = torch.full((B, Ho, Ho, cout), float("nan"), dtype=tdt, device=device)
+    if (cin, cexp, H, stride) == (128, 256, 14, 1):
+        # this shape runs in the register-resident residual kernel, which takes its weights as packages
+        pk = _rblock_packages(lib, code, cin, cexp, w1, b1, s1, w2, b2, s2, w3, b3).to(device)
+        _lib.check(lib.mfn_op_rblock(code, cin, cexp, H, xd.data_ptr(), pk.data_ptr(), 1, out.data_ptr(), B, stream(device)),
+                   "rblock")
+        torch.cuda.synchronize()
+        close(out, ref, 3 * rel, f"rblock {cin}->{cexp}->{cout} H={H}")
+        return
     _lib.check(lib.mfn_op_block(code, cin, cexp, cout, H, stride, int(res), xd.data_ptr(), w1d.data_ptr(),
                                 b1d.data_ptr(), s1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), s2d.data_ptr(),
                                 w3d.data_ptr(), b3d.data_ptr(), out.data_ptr(), B, stream(device)), "block")

@@ -103,6 +103,26 @@ def test_batch_1024_rows_match_small_batches(hip_model, device):
     assert torch.equal(full[300:500], mid)
 
 
+def test_chained_and_per_block_launches_agree_bit_for_bit(hip_model, device):
+    """conv_4's six blocks as one register-resident launch (large batches) vs six launches: same rows; and the
+    launch plan says which of the two a batch size gets."""
+    x = torch.from_numpy(synthetic.make_crops(150, 19)).to(device)
+    want = hip_model(x).cpu()
+    plan = hip_model.launch_plan(150)
+    names = [r[0] for r in hip_model.op_table()]
+    first = names.index("conv_4.model.0")
+    assert plan[first:first + 6] == [first] * 6                       # one launch covers the six blocks
+    assert hip_model.launch_plan(8) == list(range(len(names)))        # small batch: one launch per op
+    hip_model.set_chain(False)
+    try:
+        assert hip_model.launch_plan(150) == list(range(len(names)))
+        assert torch.equal(hip_model(x).cpu(), want)
+    finally:
+        hip_model.set_chain(True)
+    assert torch.equal(hip_model(x[:8].contiguous()).cpu(), want[:8])  # 2-row bands
+    assert torch.equal(hip_model(x[:60].contiguous()).cpu(), want[:60])  # 7-row bands
+
+
 def test_band_configurations_agree_bit_for_bit(hip_model, device):
     """The block kernels run short bands while those fit the chip in one go (up to 18 or 36 images, depending on
     the layer) and tall bands beyond: batches on every side of both limits give the same rows."""
