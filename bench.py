@@ -99,6 +99,34 @@ def per_kernel_profile(net, x, reps, dt):
     return groups, float(ms.sum())
 
 
+def roofline_by_class(groups, B):
+    """The two layer classes the forward is judged on, from the per-kernel event times.  Depthwise and pointwise
+    convs run FUSED in the block kernels (and conv_6_sep + GDConv in the tail kernel), so both classes are carried by
+    the same launches: the depthwise class is priced on those launches' HBM traffic, the pointwise class on the
+    matrix-core work (1x1 convs + embedding head only; depthwise and stem multiply-adds are not counted)."""
+    pw_flops_per_face = 2.0 * sum(c.cin * c.cout * c.hout * c.hout for c in layers.all_convs()
+                                  if c.k == 1 and c.groups == 1)
+    blk = [v for v in groups.values() if v["kind"] in ("block", "tail", "pw", "dw3x3", "gdconv7")]
+    lin = [v for v in groups.values() if v["kind"] == "linear"]
+    stem = [v for v in groups.values() if v["kind"] in ("stemdw", "stem")]
+
+    def hbm(vs):
+        ms, by = sum(v["ms"] for v in vs), sum(v["bytes"] for v in vs)
+        gbs = by / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "ms_per_step": round(ms, 4), "algorithmic_bytes": round(by), "achieved": round(gbs, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+    ms_mm = sum(v["ms"] for v in blk + lin)
+    fl = pw_flops_per_face * B + sum(v["flops"] for v in lin)
+    tf = fl / (ms_mm * 1e-3) / 1e12
+    out = {"depthwise_3x3_and_gdconv": dict(hbm(blk), kernels="fused block kernels + tail kernel"),
+           "pointwise_1x1_and_linear": {"bound": "mfma", "ms_per_step": round(ms_mm, 4), "flops": fl, "achieved": round(tf, 1),
+                                        "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+                                        "kernels": "fused block kernels + tail kernel + embedding head"},
+           "stem": hbm(stem)}
+    return out
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -162,10 +190,28 @@ def gallery_chunk(c, dev):
     return r / r.norm(dim=1, keepdim=True)
 
 
-def run_search(args, rank, world, dev, dist_mod):
+def sampled_bruteforce(q, gal_chunks, total, k, sample, dev):
+    """fp32 brute force (torch matmul on the device, chunk by chunk) for every `sample`-th query: the check beside
+    a search timing.  Returns (top-1 agreement helper tensors) idx [n,k] int64 and dist [n,k] of the exact top-k."""
+    qs = q[::sample]
+    best_d = torch.full((qs.shape[0], k), float("inf"), device=dev)
+    best_i = torch.full((qs.shape[0], k), -1, dtype=torch.int64, device=dev)
+    qn = (qs * qs).sum(1, keepdim=True)
+    for c in range((total + CHUNK_ROWS - 1) // CHUNK_ROWS):
+        rows = gal_chunks(c, dev)[: min(CHUNK_ROWS, total - c * CHUNK_ROWS)].half().float()   # the stored (fp16) values
+        d = qn + (rows * rows).sum(1)[None, :] - 2.0 * (qs @ rows.t())
+        cd, ci = torch.topk(d, k, dim=1, largest=False)
+        alld = torch.cat([best_d, cd], 1)
+        alli = torch.cat([best_i, ci + c * CHUNK_ROWS], 1)
+        o = torch.argsort(alld, dim=1, stable=True)[:, :k]
+        best_d, best_i = torch.gather(alld, 1, o), torch.gather(alli, 1, o)
+    return best_d, best_i
+
+
+def run_search(args, rank, world, dev, dist_mod, total=None, check_sample=0):
     from face_recognition_amd.facebank import Gallery
     from face_recognition_amd.sharded import ShardedGallery, shard_bounds
-    total = args.gallery_rows
+    total = args.gallery_rows if total is None else total
     b, e = shard_bounds(total, world, rank)
     gal = Gallery(None, n=e - b, d=512, store="f16", device=dev, index_base=b)
     t0 = time.perf_counter()
@@ -194,6 +240,18 @@ def run_search(args, rank, world, dev, dist_mod):
     d, i = sg.search(q, 5)          # warm-up + correctness of the planted half
     torch.cuda.synchronize()
     hit = float((i[: Q // 2, 0].to(torch.int64) == pick).float().mean())
+    check = None
+    if check_sample and world == 1:
+        # every check_sample-th query (planted and random halves alike) against an fp32 brute force over all rows
+        bd, bi = sampled_bruteforce(q, gallery_chunk, total, 5, check_sample, dev)
+        mine_i, mine_d = i[::check_sample].to(torch.int64), d[::check_sample]
+        same = mine_i[:, 0] == bi[:, 0]
+        near = (mine_d[:, 0] - bd[:, 0]).abs() < 1e-3          # a different row at (nearly) the same distance
+        recall = float(np.mean([len(set(a) & set(b)) / 5.0 for a, b in zip(mine_i.tolist(), bi.tolist())]))
+        check = {"queries_checked": int(same.numel()), "top1_identical": round(float(same.float().mean()), 5),
+                 "top1_identical_or_near_tie_1e-3": round(float((same | near).float().mean()), 5),
+                 "top5_recall": round(recall, 5), "against": "fp32 brute force over all rows (torch, on the device)"}
+        del bd, bi
     if world > 1:
         dist_mod.barrier()
     torch.cuda.synchronize()
@@ -211,7 +269,8 @@ def run_search(args, rank, world, dev, dist_mod):
     gal.close()
     return {"metric": "1:N top-5 queries/sec", "value": round(Q / el, 1), "unit": "queries/s", "queries": Q,
             "gallery_rows": total, "rows_per_gpu": e - b, "k": 5, "gallery_dtype": "f16", "ms_per_batch": round(el * 1e3, 3),
-            "scaling": "strong", "planted_top1_hit_rate": round(hit, 5), "gallery_build_s": round(build_s, 2),
+            "scaling": "strong", "planted_top1_hit_rate": round(hit, 5), "bruteforce_check": check,
+            "gallery_build_s": round(build_s, 2),
             "merge": (("RCCL" if dist_mod.get_backend() == "nccl" else dist_mod.get_backend()) + " all_gather + fb_merge_topk") if world > 1 else "none (1 shard)",
             "roofline": {"bound": "mfma", "achieved": round(flops / el / 1e12, 2), "peak": MFMA_PEAK_TFLOPS * world,
                          "unit": "TFLOP/s", "frac": round(flops / el / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
@@ -400,14 +459,22 @@ def main():
         groups, total_ms = per_kernel_profile(net, x, 10, args.dtype)
         dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
         gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-        traffic = None   # HBM bytes per launch from rocprofv3 PMC passes (profiles/, separate runs of this command)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
-        except OSError:
-            pass
+        # HBM bytes per launch come from rocprofv3 PMC passes of this command (separate runs, scripts/gpu_traffic.sh):
+        # the newest committed summary that knows the kernel, named in traffic_source; null when none does
+        traffic, traffic_source = None, None
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            try:
+                with open(path) as f:
+                    t = json.load(f)["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
+            except (OSError, ValueError, KeyError):
+                continue
+            if t is not None:
+                traffic, traffic_source = t, os.path.relpath(path, ROOT)
+                break
         result["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": dom_name,
+                              "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                              "kernel": dom_name,
                               "mfma_tflops": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 1),
                               "mfma_frac": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                               "launches_per_step": dom["launches"],
@@ -418,11 +485,14 @@ def main():
                                  "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
                                  "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in groups.items()}
         result["sum_kernel_ms"] = round(total_ms, 4)
+        result["roofline_by_class"] = roofline_by_class(groups, B)
         if not args.no_latency:
             result["latency_us"] = latency(net, dev)
             result["verification_10fold"] = verification_timing(dev)
             result["verification_12k_pairs"] = verification_12k(net, dev)
     if not args.no_search:
+        if world == 1:      # BASELINE configs[3]: 10k queries x 1M fp16 rows, top-5, one GPU
+            result["search_1m"] = run_search(args, rank, world, dev, dist, total=1_000_000, check_sample=40)
         s = run_search(args, rank, world, dev, dist)
         if rank == 0:
             result["search"] = s

@@ -34,13 +34,17 @@
 
 namespace fra {
 
+#ifndef RB_EXP_PD
+#define RB_EXP_PD 3        // expand stage: fragment reads run this many steps ahead of their MFMAs
+#endif
+
 // ---- expand stage: E[16-channel tile][pixels] = PReLU(W1 . X + b1) for tiles T0 .. T0 + NTT - 1 of the slice ----
 // LDS reads in issue order: bias quads, slope quads, then one A fragment per step S = (tile, k-step), PD steps
 // ahead of its MFMAs through a ring of NB registers.  LDS returns in order, so the wait of step S (at most
 // `outstanding(S)` reads in flight) also covers every quad.
 template <typename T, int KS, int PW1, int T0, int NTT> struct Exp16 {
     typedef typename vec8<T>::type V8;
-    static constexpr int NS = NTT * KS, PD = 3, NB = PD + 1;
+    static constexpr int NS = NTT * KS, PD = RB_EXP_PD, NB = PD + 1;
     static_assert(NTT % 2 == 0 && NS > PD, "tiles are written in pairs (one 16-byte unit per pair)");
     V8 fr[NB];
     f32x4 bq[NTT], sl[NTT];
@@ -160,6 +164,9 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
         }
     };
     stage(0, 0);
+#ifdef RB_PRIO_YOUNG
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses issue arbitration otherwise
+#endif
 
     // the activation image starts as zeros: border slots and out-of-image rows are never written afterwards
     for (int i = tid; i < ES_BYTES / 16; i += NW * 64) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -276,14 +283,22 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
             for (int c = 0; c < NCH; ++c, ++p) {
                 const int buf = c & 1;                         // NCH is even: the parity carries across blocks and images
                 // next package into the other buffer (last read before the previous barrier)
+#ifndef RB_ABL_NO_STAGE
                 if (p + 1 < npk) stage(p + 1, buf ^ 1);
                 else if (has_next) stage(0, buf ^ 1);
+#endif
+#ifndef RB_ABL_NO_EXPAND
                 expand(buf);
+#endif
                 // the image of this slice is complete.  Not __syncthreads(): its fence would also wait for the LDS-DMA in flight
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef RB_ABL_NO_BARRIER1
                 __builtin_amdgcn_s_barrier();
+#endif
                 asm volatile("" ::: "memory");
+#ifndef RB_ABL_NO_DW
                 dwproject(buf);
+#endif
                 if (c == NCH - 1 && dw_active) {
                     // ---- epilogue in registers: x <- round((acc + x) + b3), channel for channel what the lane holds ----
                     QuadLoad<NT16> bq3;                        // b3 of channels 16 n + 4 g ..
@@ -315,7 +330,9 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef RB_ABL_NO_BARRIER2
                 __syncthreads();                               // image free, next package visible
+#endif
             }
         }
     }
@@ -365,16 +382,19 @@ static int launch_rblock_cfg(const void* x, const void* wp, int nblk, void* out,
     return FRA_OK;
 }
 
+#ifndef RB_NW_WHOLE
+#define RB_NW_WHOLE 8      // waves of a whole-image workgroup (7 tiles of two rows; the eighth wave only stages)
+#endif
 // conv_4 (128 -> 256 -> 128 on 14 x 14): bands of 2 rows (7 workgroups per image) while those fit the chip in
 // one go, bands of 7 rows (2 per image) while those do, whole images beyond
 template <typename T>
 static int launch_rblock_t(int c, int cexp, int h, const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s) {
     const int cus = rb_compute_units();
     if (c == 128 && cexp == 256 && h == 14) {
-        if (nblk > 1) return launch_rblock_cfg<T, 128, 256, 14, 14, 8>(x, wp, nblk, out, B, s);
+        if (nblk > 1) return launch_rblock_cfg<T, 128, 256, 14, 14, RB_NW_WHOLE>(x, wp, nblk, out, B, s);
         if ((int64_t)B * 7 <= cus) return launch_rblock_cfg<T, 128, 256, 14, 2, 8>(x, wp, 1, out, B, s);
         if ((int64_t)B * 2 <= cus) return launch_rblock_cfg<T, 128, 256, 14, 7, 8>(x, wp, 1, out, B, s);
-        return launch_rblock_cfg<T, 128, 256, 14, 14, 8>(x, wp, 1, out, B, s);
+        return launch_rblock_cfg<T, 128, 256, 14, 14, RB_NW_WHOLE>(x, wp, 1, out, B, s);
     }
     FRA_REQUIRE(false, FRA_ERR_ARG, "rblock: no kernel for c=%d cexp=%d h=%d", c, cexp, h);
     return FRA_ERR_ARG;

@@ -291,5 +291,11 @@ def test_bench_line_contract():
         assert key in r, key
     assert r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1 and r["unit"] == "faces/s" and r["value"] > 0
     assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None and "workload" in r["config"]
+    assert "traffic_source" in r["roofline"] and "traffic" in r["roofline"]
+    by_class = r["roofline_by_class"]
+    assert set(by_class) == {"depthwise_3x3_and_gdconv", "pointwise_1x1_and_linear", "stem"}
+    for cls in by_class.values():
+        assert cls["bound"] in ("hbm", "mfma") and abs(cls["frac"] - cls["achieved"] / cls["peak"]) < 1e-3
+    assert by_class["pointwise_1x1_and_linear"]["bound"] == "mfma" and by_class["depthwise_3x3_and_gdconv"]["bound"] == "hbm"
     rf = r["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
