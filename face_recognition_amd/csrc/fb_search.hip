@@ -530,6 +530,17 @@ static int fill_rows(fb_handle* h, int64_t row0, const float* src, int is_device
     return rc;
 }
 
+// compute units of the current device (asked once per device)
+static int search_compute_units() {
+    static std::atomic<int> cus_of[64];
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev < 64 && (cus = cus_of[dev].load(std::memory_order_relaxed)) > 0) return cus;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (dev < 64) cus_of[dev].store(cus, std::memory_order_relaxed);
+    return cus;
+}
+
 // Scratch of one search: `fixed` == nullptr takes (and grows) the handle's own block; otherwise the search must
 // fit the `cap` bytes at `fixed` and nothing is allocated.
 static int take_scratch(fb_handle* h, size_t need, char* fixed, size_t cap, char** out) {
@@ -564,11 +575,21 @@ static int search_packed(fb_handle* h, const float* queries, int Q, int k, float
     const int QT = (Q + BQ - 1) / BQ, Qpad = QT * BQ;
     const int tiles = (int)(h->Npad / BG);
     const int KS = k == 1 ? 1 : (k <= 5 ? 5 : 8);
-    // splits: enough blocks to fill the chip a few times over, at most 64 (=> 256 lists per query)
-    int S = (1024 + QT - 1) / QT;
-    if (S > 64) S = 64;
-    if (S > tiles) S = tiles;
-    if (S >= 8) S &= ~7;  // multiple of 8 enables the XCD-aware block mapping
+    // Gallery splits.  A block occupies a compute unit alone (LDS) and all blocks of a search do equal work, so the
+    // grid should be a whole number of rounds over the chip: among the multiples of 8 (the XCD-aware block mapping)
+    // up to 64 (=> 256 partial lists per query) take the split count that wastes the least of its last round, the
+    // smaller one on ties; a gallery of fewer than 8 tiles gets one split per tile.
+    int S = tiles < 8 ? tiles : 8;
+    if (tiles >= 8) {
+        const int cus = search_compute_units();
+        double best = -1.0;
+        for (int cand = 8; cand <= 64 && cand <= tiles; cand += 8) {
+            const long blocks = (long)QT * cand;
+            const long rounds = (blocks + cus - 1) / cus;
+            const double eff = (double)blocks / (double)(rounds * cus);
+            if (eff > best + 1e-9) { best = eff; S = cand; }
+        }
+    }
     const int tps = (tiles + S - 1) / S;
     S = (tiles + tps - 1) / tps;  // drop empty splits
     const int P = 4 * S;   // four partial lists (lane groups) per split
