@@ -35,20 +35,23 @@ def getThreshold(scores, flags, thrNum, method):
 
     The reference evaluates getAccuracy at each of the 2*thrNum+1 thresholds.  #(s < t) and #(s > t)
     over a sorted array are two binary searches, so all accuracies come from four searchsorted
-    calls; the comparisons are made in float64 against the float64 grid, as numpy does for a
-    float32 array compared with a float64 scalar, so every count -- and the result -- is identical.
+    calls.  The comparisons are made in the type numpy gives ``scores < thresholds[i]`` in the reference's
+    loop -- float64 under NumPy >= 2 promotion, the array's own type under NumPy 1.x value-based casting
+    of the scalar -- so every count, and the result, is identical under either.
     """
     if method not in ("l2_distance", "cos_distance"):
         raise ValueError(f"unknown method {method!r}")
     scores = np.asarray(scores)
     flags = np.asarray(flags)
     thresholds = np.arange(-thrNum, thrNum + 1) * 3.0 / thrNum
-    pos = np.sort(scores[flags == 1].astype(np.float64))
-    neg = np.sort(scores[flags == -1].astype(np.float64))
-    pos_lt = np.searchsorted(pos, thresholds, side="left")
-    pos_gt = len(pos) - np.searchsorted(pos, thresholds, side="right")
-    neg_lt = np.searchsorted(neg, thresholds, side="left")
-    neg_gt = len(neg) - np.searchsorted(neg, thresholds, side="right")
+    cmp = np.result_type(scores[:0], thresholds[0])       # an array against a float64 SCALAR, as in the reference's loop
+    pos = np.sort(scores[flags == 1].astype(cmp))
+    neg = np.sort(scores[flags == -1].astype(cmp))
+    grid = thresholds.astype(cmp)
+    pos_lt = np.searchsorted(pos, grid, side="left")
+    pos_gt = len(pos) - np.searchsorted(pos, grid, side="right")
+    neg_lt = np.searchsorted(neg, grid, side="left")
+    neg_gt = len(neg) - np.searchsorted(neg, grid, side="right")
     if np.isnan(pos).any() or np.isnan(neg).any():
         # NaN compares false both ways; searchsorted would put it last and count it as "greater"
         pos_gt = pos_gt - int(np.isnan(pos).sum())
@@ -90,7 +93,10 @@ def evaluation_10_fold(featureL, featureR, dataset, method="l2_distance"):
     accumulates across folds exactly as it does there.
     """
     if isinstance(featureL, torch.Tensor) and featureL.is_cuda:
-        return _evaluation_10_fold_device(featureL, featureR, dataset, method)
+        if featureL.dim() == 2 and featureL.shape[1] in (128, 256, 512):
+            return _evaluation_10_fold_device(featureL, featureR, dataset, method)
+        # widths the device kernel does not take (embedding_size 1024): the reference's host arithmetic
+        featureL, featureR = featureL.cpu(), featureR.cpu()
     ACCs = np.zeros(10)
     threshold = np.zeros(10)
     fold = np.array(dataset.folds).reshape(1, -1)

@@ -48,7 +48,9 @@ def allgather_topk(local_dist: torch.Tensor, local_idx: torch.Tensor, group=None
     packed[:, :k] = local_dist.contiguous().view(torch.int32)
     packed[:, k:] = local_idx.to(torch.int32)
     if packed.is_cuda and dist.get_backend(group) == "gloo":
-        # gloo moves device tensors through the host itself, and its device path hangs on this stack: stage them here
+        # gloo moves device tensors through the host itself.  Two gloo ranks that share ONE GPU (the one-GPU rehearsal
+        # of the multi-rank path) block for ever inside its device path when the library's launches are still queued
+        # and nothing torch launched follows them; the copy to the host synchronises first, which avoids that
         host = torch.empty((world, q, 2 * k), dtype=torch.int32)
         dist.all_gather_into_tensor(host.view(world * q, 2 * k), packed.cpu(), group=group)
         gathered = host.to(packed.device)

@@ -1,0 +1,78 @@
+"""The counterpart of the reference's test_lfw_agedb_cfpfp.py (load ckpt['net_state_dict'], bs 50, flip,
+cos_distance, one line per phase): data layout and checkpoint forms on the CPU, the harness itself on the GPU
+against the oracle."""
+import io
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from face_recognition_amd import synthetic
+from face_recognition_amd import test_lfw_agedb_cfpfp as harness
+from face_recognition_amd.face_model import MobileFaceNet
+
+
+def test_pair_sets_have_the_reference_layout():
+    loaders, sizes, sets = harness.load_test_data(50)
+    assert sizes == {"LFW": 6000, "CFP_FP": 7000, "AgeDB30": 6000}          # dataloader.py:22-160
+    cfp = sets["CFP_FP"]
+    assert cfp.folds[0] == 0 and cfp.folds[699] == 0 and cfp.folds[700] == 1 and cfp.folds[6999] == 9   # i // 700 (:90)
+    assert sets["LFW"].folds[599] == 0 and sets["LFW"].folds[600] == 1                                  # i // 600 (:41)
+    assert set(cfp.flags) == {1, -1} and sum(cfp.flags) == 0
+    assert len(loaders["CFP_FP"]) == 140 and len(loaders["LFW"]) == 120                                 # bs 50 (:60)
+    small = harness.SyntheticPairs(40, seed=3)
+    a, b = small.batch(20, 50), small.batch(20, 50)
+    assert len(a) == 4 and a[0].shape == (20, 3, 112, 112) and a[0].dtype == torch.float32
+    assert all(torch.equal(x, y) for x, y in zip(a, b))                      # a batch is a function of its arguments
+    assert torch.equal(a[1], torch.flip(a[0], dims=[3])) and torch.equal(a[3], torch.flip(a[2], dims=[3]))
+    assert float(a[0].abs().max()) <= 1.0
+    got = list(harness.PairLoader(small, 16))
+    assert [g[0].shape[0] for g in got] == [16, 16, 8]
+
+
+def test_checkpoint_forms(tmp_path):
+    """test_lfw_agedb_cfpfp.py:62 reads ckpt['net_state_dict']; DataParallel checkpoints carry 'module.' (:63-67)."""
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(3, 512).items()}
+    forms = {"plain": sd, "wrapped": {"iters": 555000, "net_state_dict": sd},
+             "module": {"net_state_dict": {"module." + k: v for k, v in sd.items()}}}
+    for name, obj in forms.items():
+        path = tmp_path / f"{name}.ckpt"
+        torch.save(obj, path)
+        m = MobileFaceNet(512)
+        m.load_state_dict(harness.load_checkpoint(str(path)))
+        assert torch.equal(m.state_dict()["conv_4.model.3.conv_dw.bn.running_var"], sd["conv_4.model.3.conv_dw.bn.running_var"])
+
+
+@pytest.mark.gpu
+def test_harness_against_oracle(hip_model, device, state_dict_np):
+    """Three phases of 1000 / 1400 / 1000 pairs (fold = i // 100, 140, 100): the printed mean accuracy is within
+    0.1 pt of the fp32 oracle's on the same crops, for every phase."""
+    from oracle import evaluation_ref, mobilefacenet_ref
+    sizes = {"LFW": 1000, "CFP_FP": 1400, "AgeDB30": 1000}
+    out = io.StringIO()
+    res = harness.run(hip_model, device, batch_size=50, sizes=sizes, seed=5, noise=0.3, out=out)
+    lines = out.getvalue().strip().splitlines()
+    assert len(lines) == 3
+    _, _, sets = harness.load_test_data(50, sizes=sizes, seed=5, noise=0.3, device=device)
+    embed = lambda x: mobilefacenet_ref.forward(state_dict_np, x)      # noqa: E731
+    for line, (phase, ds) in zip(lines, sets.items()):
+        m = re.match(r"Epoch 1/1，(\w+) average acc:([\d.]+) average threshold:(-?[\d.]+)", line)
+        assert m and m.group(1) == phase, line
+        cpu_batches = ([t.cpu() for t in b] for b in harness.PairLoader(ds, 200))
+        ol, orr = evaluation_ref.get_feature(embed, cpu_batches, flip=True)
+        oacc, othr = evaluation_ref.evaluation_10_fold(ol.numpy(), orr.numpy(), ds.folds, ds.flags, "cos_distance")
+        print(line, "| oracle acc %.4f thr %.4f" % (oacc.mean() * 100, othr.mean()))
+        assert abs(float(m.group(2)) - oacc.mean() * 100) <= 0.1 + 1e-4
+        assert abs(float(m.group(3)) - othr.mean()) < 5e-3
+        assert abs(res[phase][0].mean() * 100 - float(m.group(2))) < 1e-4
+
+
+@pytest.mark.gpu
+def test_harness_full_size_phases_run(hip_model, device):
+    """The reference's sizes -- 6000, 7000 (fold = i // 700) and 6000 pairs at batch size 50 with flip."""
+    out = io.StringIO()
+    res = harness.run(hip_model, device, batch_size=50, seed=1, out=out)
+    assert list(res) == ["LFW", "CFP_FP", "AgeDB30"] and len(out.getvalue().strip().splitlines()) == 3
+    for accs, thr in res.values():
+        assert accs.shape == (10,) and np.isfinite(accs).all() and np.isfinite(thr).all() and 0.5 < accs.mean() <= 1.0
