@@ -51,6 +51,59 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _worker_small(rank, world, port, out_dir, n):
+    """Uneven shards, some holding fewer than K rows: their lists carry (inf, -1) in the missing slots, as the HIP
+    search reports them, and the merge must skip those."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = synthetic.unit_rows(n, 64, seed=13)
+        q = synthetic.unit_rows(9, 64, seed=15)
+        b, e = sharded.shard_bounds(n, world, rank)
+
+        def local_search(queries, k):
+            d, i = matching_ref.l2_topk_bruteforce(queries.numpy(), g[b:e], k)
+            dd = np.full((queries.shape[0], k), np.inf, dtype=np.float32)
+            ii = np.full((queries.shape[0], k), -1, dtype=np.int32)
+            dd[:, : d.shape[1]] = d
+            ii[:, : i.shape[1]] = i + b
+            return torch.from_numpy(dd), torch.from_numpy(ii)
+
+        def merge(dp, ip, k):
+            d, i = matching_ref.merge_topk(dp.numpy(), ip.numpy(), k)
+            return torch.from_numpy(d.astype(np.float32)), torch.from_numpy(i.astype(np.int32))
+
+        sg = sharded.ShardedGallery(n, local_search, merge=merge)
+        d, i = sg.search(torch.from_numpy(q), K)
+        lo, hi = sharded.split_batch(10)              # 10 crops over 4 ranks: 3, 3, 2, 2
+        emb = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 4)
+        allemb = sharded.gather_embeddings(emb, 10)
+        np.savez(os.path.join(out_dir, f"s{rank}.npz"), d=d.numpy(), i=i.numpy(), allemb=allemb.numpy(), bounds=np.array([b, e]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_search_four_ranks_uneven_and_short_shards(tmp_path):
+    """World 4.  11 rows -> shards of 3, 3, 3, 2 rows, every one shorter than k = 5; 5003 rows -> 1251, 1251, 1251, 1250."""
+    world = 4
+    assert [sharded.shard_bounds(11, world, r) for r in range(world)] == [(0, 3), (3, 6), (6, 9), (9, 11)]
+    assert [e - b for b, e in (sharded.shard_bounds(5003, world, r) for r in range(world))] == [1251, 1251, 1251, 1250]
+    for n in (11, 5003):
+        out = tmp_path / f"n{n}"
+        out.mkdir()
+        mp.spawn(_worker_small, args=(world, _free_port(), str(out), n), nprocs=world, join=True)
+        g = synthetic.unit_rows(n, 64, seed=13)
+        q = synthetic.unit_rows(9, 64, seed=15)
+        bd, bi = matching_ref.l2_topk_bruteforce(q, g, K)
+        rs = [np.load(out / f"s{r}.npz") for r in range(world)]
+        for r in rs:
+            assert np.array_equal(r["i"], rs[0]["i"]) and np.array_equal(r["d"], rs[0]["d"])
+            assert np.array_equal(r["allemb"][:, 0], np.arange(10, dtype=np.float32))
+        assert np.array_equal(rs[0]["i"], bi) and (rs[0]["i"] >= 0).all()
+        assert np.allclose(rs[0]["d"], bd, atol=1e-5)
+        assert sorted(tuple(r["bounds"]) for r in rs)[-1][1] == n
+
+
 def test_sharded_search_two_ranks(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
