@@ -54,6 +54,7 @@ SIGNATURES = {
     "mfn_op_linear_l2norm": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fb_create": (_I, [C.POINTER(_P), _I, _P, _I, _L, _I, _I, _L]),
     "fb_fill": (_I, [_P, _L, _P, _I, _L]),
+    "fb_fill_async": (_I, [_P, _L, _P, _L, _P]),
     "fb_rows": (_L, [_P]),
     "fb_reserve": (_I, [_P, _I]),
     "fb_export_packed": (_I, [_P, _L, _L, _P, _I, _P, _I]),

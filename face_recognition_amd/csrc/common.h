@@ -70,6 +70,24 @@ const char* last_error();
         }                                                                                      \
     } while (0)
 
+// Makes `device` current for the lifetime of the object and restores the caller's device afterwards: an entry point
+// must not leave the thread on another device than it found it on (PyTorch keeps its own idea of the current one).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+        else if (err == hipSuccess) prev = -1;             // nothing to restore
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define FRA_DEVICE(device)                 \
+    fra::DeviceGuard guard__(device);      \
+    FRA_HIP(guard__.err)
+
 // A kernel's dynamic-LDS limit is a property of the kernel ON ONE DEVICE: raise it the first time the kernel
 // is launched on each device of the process (bit d of `done` = device d has it; devices past 63 set it on
 // every launch).  *device, if given, receives the current device.

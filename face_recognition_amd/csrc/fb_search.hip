@@ -28,6 +28,7 @@ struct fb_handle {
     size_t scratch_bytes = 0;
     void* retired[32] = {nullptr};
     int n_retired = 0;
+    hipStream_t copy_stream = nullptr;   // fb_create / fb_fill pack rows here, so they never synchronise other streams
 };
 
 namespace fra {
@@ -493,38 +494,50 @@ static int ensure_scratch(fb_handle* h, size_t bytes) {
     return FRA_OK;
 }
 
-static int fill_rows(fb_handle* h, int64_t row0, const float* src, int is_device, int64_t n) {
+template <typename T>
+static void launch_pack(const float* src, fb_handle* h, int64_t row0, int64_t m, hipStream_t s) {
+    hipLaunchKernelGGL(pack_rows_kernel<T>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, src,
+                       static_cast<T*>(h->rows) + row0 * h->D, h->negh + row0, (long)m, h->D);
+}
+
+// Rows [row0, row0 + n) <- src.  `ordered` != nullptr: device rows, everything is queued on that stream and nothing
+// is waited for.  Otherwise the work goes to the handle's own stream, which is synchronised before returning (the
+// other streams of the process are left alone); the caller must have finished writing device rows.
+static int fill_rows(fb_handle* h, int64_t row0, const float* src, int is_device, int64_t n, const hipStream_t* ordered = nullptr) {
     FRA_REQUIRE(row0 >= 0 && n >= 0 && row0 + n <= h->N, FRA_ERR_ARG, "fb_fill: rows [%lld,%lld) outside [0,%lld)",
                 (long long)row0, (long long)(row0 + n), (long long)h->N);
     if (n == 0) return FRA_OK;
-    FRA_HIP(hipSetDevice(h->device));
+    FRA_DEVICE(h->device);
     const int D = h->D;
+    if (!ordered && !h->copy_stream) FRA_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    hipStream_t s = ordered ? *ordered : h->copy_stream;
     if (h->store == FRA_F32) {
-        FRA_HIP(hipMemcpy(static_cast<float*>(h->rows) + row0 * D, src, (size_t)n * D * 4,
-                          is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        FRA_HIP(hipMemcpyAsync(static_cast<float*>(h->rows) + row0 * D, src, (size_t)n * D * 4,
+                               is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+        if (!ordered) FRA_HIP(hipStreamSynchronize(s));
         return FRA_OK;
     }
     const int64_t step = is_device ? n : (int64_t)(64 << 20) / (D * 4);  // host data goes through a 64 MB bounce
     float* bounce = nullptr;
     if (!is_device) FRA_HIP(hipMalloc(&bounce, (size_t)step * D * 4));
     int rc = FRA_OK;
-    for (int64_t s = 0; s < n && rc == FRA_OK; s += step) {
-        const int64_t m = (n - s) < step ? (n - s) : step;
-        const float* dsrc = src + s * D;
+    for (int64_t o = 0; o < n && rc == FRA_OK; o += step) {
+        const int64_t m = (n - o) < step ? (n - o) : step;
+        const float* dsrc = src + o * D;
         if (!is_device) {
-            hipError_t e = hipMemcpy(bounce, src + s * D, (size_t)m * D * 4, hipMemcpyHostToDevice);
-            if (e != hipSuccess) { set_error("fb_fill: hipMemcpy failed: %s", hipGetErrorString(e)); rc = FRA_ERR_HIP; break; }
+            // the previous chunk's pack kernel (same stream) has read the bounce buffer before this copy overwrites it
+            hipError_t e = hipMemcpyAsync(bounce, src + o * D, (size_t)m * D * 4, hipMemcpyHostToDevice, s);
+            if (e != hipSuccess) { set_error("fb_fill: copy to the device failed: %s", hipGetErrorString(e)); rc = FRA_ERR_HIP; break; }
             dsrc = bounce;
         }
-        const unsigned blocks = (unsigned)((m + 3) / 4);
-        if (h->store == FRA_F16)
-            hipLaunchKernelGGL(pack_rows_kernel<f16>, dim3(blocks), dim3(256), 0, 0, dsrc,
-                               static_cast<f16*>(h->rows) + (row0 + s) * D, h->negh + row0 + s, (long)m, D);
-        else
-            hipLaunchKernelGGL(pack_rows_kernel<bf16>, dim3(blocks), dim3(256), 0, 0, dsrc,
-                               static_cast<bf16*>(h->rows) + (row0 + s) * D, h->negh + row0 + s, (long)m, D);
-        hipError_t e = hipDeviceSynchronize();
-        if (e != hipSuccess) { set_error("fb_fill: pack kernel failed: %s", hipGetErrorString(e)); rc = FRA_ERR_HIP; }
+        if (h->store == FRA_F16) launch_pack<f16>(dsrc, h, row0 + o, m, s);
+        else launch_pack<bf16>(dsrc, h, row0 + o, m, s);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_error("fb_fill: pack kernel launch failed: %s", hipGetErrorString(e)); rc = FRA_ERR_HIP; }
+    }
+    if (!ordered || bounce) {
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess && rc == FRA_OK) { set_error("fb_fill: pack kernel failed: %s", hipGetErrorString(e)); rc = FRA_ERR_HIP; }
     }
     if (bounce) (void)hipFree(bounce);
     return rc;
@@ -623,22 +636,38 @@ static int search_packed(fb_handle* h, const float* queries, int Q, int k, float
     return FRA_OK;
 }
 
+// fp32 path: the Q x N distance matrix is produced and selected from in chunks of queries, so the scratch stays
+// within F32_SCRATCH_CAP whatever Q is (one query's row of distances must fit)
+static const size_t F32_SCRATCH_CAP = (size_t)256 << 20;
 static int search_f32(fb_handle* h, const float* queries, int Q, int k, float* dist_out, int32_t* idx_out,
                       hipStream_t s, char* fixed, size_t cap) {
-    const size_t bytes = (size_t)Q * h->N * 4;
+    FRA_REQUIRE(h->N < 2147483647L, FRA_ERR_ARG, "fb_search: gallery too large");
+    const size_t row_bytes = (size_t)h->N * 4;
+    const size_t budget = fixed ? cap : F32_SCRATCH_CAP;
+    FRA_REQUIRE(row_bytes <= budget, FRA_ERR_ARG,
+                "%s: an fp32 gallery of %lld rows needs %zu bytes of scratch per query, more than the %zu available; "
+                "store it as f16 / bf16", fixed ? "fb_search_l2_topk_noalloc" : "fb_search", (long long)h->N, row_bytes, budget);
+    int qc = (int)(budget / row_bytes);                    // queries per chunk
+    if (qc > Q) qc = Q;
+    if (fixed)      // the entry point that must not allocate takes what fits in one chunk only
+        FRA_REQUIRE(qc == Q, FRA_ERR_ARG,
+                    "fb_search_l2_topk_noalloc: this search needs %zu bytes of scratch, the static array holds %zu; "
+                    "use fb_search_l2_topk (fewer queries, or a smaller fp32 gallery, fit)", (size_t)Q * row_bytes, cap);
     char* sc = nullptr;
-    int rc = take_scratch(h, align_up(bytes, 256), fixed, cap, &sc);
+    int rc = take_scratch(h, align_up((size_t)qc * row_bytes, 256), fixed, cap, &sc);
     if (rc) return rc;
     float* dist = reinterpret_cast<float*>(sc);
-    const long pairs = (long)Q * h->N;
-    FRA_REQUIRE((pairs + 3) / 4 < 2147483647L, FRA_ERR_ARG, "fb_search: Q*N too large for the fp32 gallery path");
-    hipLaunchKernelGGL(l2dist_f32_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, queries,
-                       static_cast<const float*>(h->rows), dist, Q, (long)h->N, h->D);
-    FRA_HIP(hipGetLastError());
-    FRA_REQUIRE(h->N < 2147483647L, FRA_ERR_ARG, "fb_search: gallery too large");
-    hipLaunchKernelGGL(select_topk_kernel, dim3(Q), dim3(256), 0, s, dist, (const int*)nullptr, 1, 0L, (long)h->N,
-                       (int)h->N, (int)h->index_base, k, dist_out, idx_out);
-    FRA_HIP(hipGetLastError());
+    for (int q0 = 0; q0 < Q; q0 += qc) {
+        const int m = (Q - q0) < qc ? (Q - q0) : qc;
+        const long pairs = (long)m * h->N;
+        FRA_REQUIRE((pairs + 3) / 4 < 2147483647L, FRA_ERR_ARG, "fb_search: Q*N too large for the fp32 gallery path");
+        hipLaunchKernelGGL(l2dist_f32_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, queries + (size_t)q0 * h->D,
+                           static_cast<const float*>(h->rows), dist, m, (long)h->N, h->D);
+        FRA_HIP(hipGetLastError());
+        hipLaunchKernelGGL(select_topk_kernel, dim3(m), dim3(256), 0, s, dist, (const int*)nullptr, 1, 0L, (long)h->N,
+                           (int)h->N, (int)h->index_base, k, dist_out + (size_t)q0 * k, idx_out + (size_t)q0 * k);
+        FRA_HIP(hipGetLastError());
+    }
     return FRA_OK;
 }
 
@@ -689,7 +718,7 @@ int fb_create(fb_handle** out, int device, const float* gallery, int gallery_is_
     int count = 0;
     FRA_HIP(hipGetDeviceCount(&count));
     FRA_REQUIRE(device >= 0 && device < count, FRA_ERR_ARG, "fb_create: device %d not in [0,%d)", device, count);
-    FRA_HIP(hipSetDevice(device));
+    FRA_DEVICE(device);
     if (device < 64) {                      // set-up: this GPU's address of the static scratch array
         char* unused = nullptr;
         if (int rc = static_scratch_ptr(device, &unused)) return rc;
@@ -704,15 +733,16 @@ int fb_create(fb_handle** out, int device, const float* gallery, int gallery_is_
         h->Npad = (N + BG - 1) / BG * BG;
         e = hipMalloc(&h->rows, (size_t)h->Npad * D * 2);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->negh), (size_t)h->Npad * 4);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
         if (e == hipSuccess && h->Npad > N) {
             const long total = (h->Npad - N) * (long)D;
             if (store_dtype == FRA_F16)
-                hipLaunchKernelGGL(pad_rows_kernel<f16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0,
+                hipLaunchKernelGGL(pad_rows_kernel<f16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->copy_stream,
                                    static_cast<f16*>(h->rows), h->negh, (long)N, (long)h->Npad, D);
             else
-                hipLaunchKernelGGL(pad_rows_kernel<bf16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0,
+                hipLaunchKernelGGL(pad_rows_kernel<bf16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->copy_stream,
                                    static_cast<bf16*>(h->rows), h->negh, (long)N, (long)h->Npad, D);
-            e = hipDeviceSynchronize();
+            e = hipStreamSynchronize(h->copy_stream);
         }
     }
     if (e != hipSuccess) {
@@ -733,6 +763,12 @@ int fb_fill(fb_handle* h, int64_t row0, const float* rows, int rows_is_device, i
     return fill_rows(h, row0, rows, rows_is_device, n);
 }
 
+int fb_fill_async(fb_handle* h, int64_t row0, const float* rows_dev, int64_t n, fra_stream stream) {
+    FRA_REQUIRE(h && rows_dev, FRA_ERR_ARG, "fb_fill_async: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return fill_rows(h, row0, rows_dev, 1, n, &s);
+}
+
 int64_t fb_rows(const fb_handle* h) { return h ? h->N : -1; }
 
 // packed rows (16-bit [n][D]) and their bias terms, exactly as the search kernel reads them
@@ -744,17 +780,21 @@ static int copy_packed(fb_handle* h, int64_t row0, int64_t n, void* rows16, int 
     FRA_REQUIRE(row0 >= 0 && n >= 0 && row0 + n <= h->N, FRA_ERR_ARG, "%s: rows [%lld,%lld) outside [0,%lld)", what,
                 (long long)row0, (long long)(row0 + n), (long long)h->N);
     if (n == 0) return FRA_OK;
-    FRA_HIP(hipSetDevice(h->device));
+    FRA_DEVICE(h->device);
     char* hr = static_cast<char*>(h->rows) + (size_t)row0 * h->D * 2;
     float* hn = h->negh + row0;
     const size_t rb = (size_t)n * h->D * 2, nb = (size_t)n * 4;
+    // on the handle's own stream, synchronised before returning: other streams of the process are not serialised
+    if (!h->copy_stream) FRA_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    hipStream_t s = h->copy_stream;
     if (to_handle) {
-        FRA_HIP(hipMemcpy(hr, rows16, rb, rows_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-        FRA_HIP(hipMemcpy(hn, negh, nb, negh_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        FRA_HIP(hipMemcpyAsync(hr, rows16, rb, rows_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+        FRA_HIP(hipMemcpyAsync(hn, negh, nb, negh_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     } else {
-        FRA_HIP(hipMemcpy(rows16, hr, rb, rows_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
-        FRA_HIP(hipMemcpy(negh, hn, nb, negh_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+        FRA_HIP(hipMemcpyAsync(rows16, hr, rb, rows_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+        FRA_HIP(hipMemcpyAsync(negh, hn, nb, negh_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
     }
+    FRA_HIP(hipStreamSynchronize(s));
     return FRA_OK;
 }
 
@@ -771,8 +811,12 @@ int fb_import_packed(fb_handle* h, int64_t row0, int64_t n, const void* rows16, 
 
 int fb_reserve(fb_handle* h, int max_queries) {
     FRA_REQUIRE(h && max_queries > 0, FRA_ERR_ARG, "fb_reserve: bad argument");
-    FRA_HIP(hipSetDevice(h->device));
-    if (h->store == FRA_F32) return ensure_scratch(h, align_up((size_t)max_queries * h->N * 4, 256));
+    FRA_DEVICE(h->device);
+    if (h->store == FRA_F32) {
+        size_t need = (size_t)max_queries * h->N * 4;
+        if (need > F32_SCRATCH_CAP) need = F32_SCRATCH_CAP;
+        return ensure_scratch(h, align_up(need, 256));
+    }
     const int QT = (max_queries + BQ - 1) / BQ, Qpad = QT * BQ;
     const size_t P = 256, KS = 8;   // upper bounds of the partial-list layout in search_packed
     return ensure_scratch(h, align_up((size_t)Qpad * h->D * 2, 256) + align_up((size_t)Qpad * 4, 256) +
@@ -784,7 +828,7 @@ int fb_search_l2_topk(fb_handle* h, const float* queries, int Q, int k, float* d
     FRA_REQUIRE(h && queries && dist_out && idx_out, FRA_ERR_ARG, "fb_search: null pointer");
     FRA_REQUIRE(Q > 0, FRA_ERR_ARG, "fb_search: Q=%d", Q);
     FRA_REQUIRE(k >= 1 && k <= 8, FRA_ERR_ARG, "fb_search: k=%d not in [1,8]", k);
-    FRA_HIP(hipSetDevice(h->device));
+    FRA_DEVICE(h->device);
     return search_any(h, queries, Q, k, dist_out, idx_out, (hipStream_t)stream, nullptr, 0);
 }
 
@@ -793,7 +837,7 @@ int fb_search_l2_topk_noalloc(fb_handle* h, const float* queries, int Q, int k, 
     FRA_REQUIRE(h && queries && dist_out && idx_out, FRA_ERR_ARG, "fb_search_l2_topk_noalloc: null pointer");
     FRA_REQUIRE(Q > 0, FRA_ERR_ARG, "fb_search_l2_topk_noalloc: Q=%d", Q);
     FRA_REQUIRE(k >= 1 && k <= 8, FRA_ERR_ARG, "fb_search_l2_topk_noalloc: k=%d not in [1,8]", k);
-    FRA_HIP(hipSetDevice(h->device));
+    FRA_DEVICE(h->device);
     char* sc = nullptr;
     if (int rc = static_scratch_ptr(h->device, &sc)) return rc;   // found at fb_create; a lookup, not an allocation
     return search_any(h, queries, Q, k, dist_out, idx_out, (hipStream_t)stream, sc, STATIC_SCRATCH_BYTES);
@@ -821,7 +865,8 @@ int fb_threshold_score(const float* minimum, int64_t* idx_io, float* score_100, 
 
 int fb_destroy(fb_handle* h) {
     if (!h) return FRA_OK;
-    (void)hipSetDevice(h->device);
+    fra::DeviceGuard guard(h->device);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->rows) (void)hipFree(h->rows);
     if (h->negh) (void)hipFree(h->negh);
     if (h->scratch) (void)hipFree(h->scratch);

@@ -450,7 +450,7 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
                 for (int k = 0; k < o.cin; ++k) dst[(size_t)oc * o.cin + k] = to16(dt, (float)(w[(size_t)oc * o.cin + k] * scale[oc]));
         }
     }
-    FRA_HIP(hipSetDevice(h->device));
+    FRA_DEVICE(h->device);
     if (h->arena_bytes < off) {
         if (h->arena) FRA_HIP(hipFree(h->arena));
         h->arena = nullptr;
@@ -579,6 +579,7 @@ static int forward(mfn_handle* h, const void* x, int x_is_u8, int B, bool tta, f
                    hipStream_t s, float* op_ms, int n_ops_timed) {
     int rc = check_forward_args(h, x, B, tta, out, ws, ws_bytes);
     if (rc) return rc;
+    FRA_DEVICE(h->device);   // launches, LDS limits and occupancy answers all belong to the handle's device
     FRA_REQUIRE(h->fused || (!tta && !x_is_u8), FRA_ERR_STATE, "uint8 input and fused flip-TTA need the fused schedule");
     const int nops = (int)h->ops().size();
     const int sl = slice_size(h, B);
@@ -741,6 +742,7 @@ int mfn_debug_prefix(mfn_handle* h, const float* x, int B, int n_ops, float* out
     FRA_REQUIRE(n_ops >= 1 && n_ops < (int)h->ops().size(), FRA_ERR_ARG,
                 "mfn_debug_prefix: n_ops %d not in [1,%d)", n_ops, (int)h->ops().size());
     FRA_REQUIRE(slice_size(h, B) == B, FRA_ERR_STATE, "mfn_debug_prefix: batch chunking must be off");
+    FRA_DEVICE(h->device);
     const WsPlan p = plan_ws(B, h->E, false);
     hipStream_t s = (hipStream_t)stream;
     for (int i = 0; i < n_ops;) {
@@ -758,7 +760,7 @@ int mfn_debug_prefix(mfn_handle* h, const float* x, int B, int n_ops, float* out
 int mfn_destroy(mfn_handle* h) {
     if (!h) return FRA_OK;
     if (h->arena) {
-        (void)hipSetDevice(h->device);
+        fra::DeviceGuard guard(h->device);
         (void)hipFree(h->arena);
     }
     delete h;

@@ -78,7 +78,7 @@ class Gallery:
             if rows is not None and rows.is_cuda and rows.device != device:
                 rows = rows.to(device)
             if rows is not None and rows.is_cuda:
-                # fb_create packs on the default stream: the rows must have been written by then
+                # fb_create packs on a stream of its own: the rows must have been written by then
                 torch.cuda.current_stream(device).synchronize()
             _lib.check(lib.fb_create(C.byref(h), device.index, rows.data_ptr() if rows is not None else None,
                                      1 if (rows is not None and rows.is_cuda) else 0, n, d,
@@ -86,11 +86,18 @@ class Gallery:
         self._h = h.value
 
     def fill(self, row0: int, rows: torch.Tensor) -> None:
+        """Write rows [row0, row0+len(rows)).  Device rows are packed on the current stream without waiting (later
+        searches on that stream see them); host rows are copied synchronously."""
         rows = rows.detach().to(torch.float32).contiguous()
         with torch.cuda.device(self.device):
-            torch.cuda.current_stream(self.device).synchronize()
-            _lib.check(_lib.load().fb_fill(self._h, int(row0), rows.data_ptr(), 1 if rows.is_cuda else 0,
-                                           int(rows.shape[0])), "fb_fill")
+            if rows.is_cuda:
+                if rows.device != self.device:
+                    rows = rows.to(self.device)
+                rows.record_stream(torch.cuda.current_stream(self.device))     # keep the block until the pack kernel has read it
+                _lib.check(_lib.load().fb_fill_async(self._h, int(row0), rows.data_ptr(), int(rows.shape[0]),
+                                                     _lib.current_stream_ptr(self.device)), "fb_fill_async")
+            else:
+                _lib.check(_lib.load().fb_fill(self._h, int(row0), rows.data_ptr(), 0, int(rows.shape[0])), "fb_fill")
 
     def reserve(self, max_queries: int) -> None:
         """Pre-size internal scratch for searches of up to ``max_queries`` queries (needed before graph capture)."""

@@ -50,6 +50,21 @@ def make_state_dict(seed: int = 1, embedding_size: int = 512) -> Dict[str, np.nd
     return {k: sd[k] for k, _, _ in L.state_dict_keys(embedding_size)}
 
 
+def with_embedding_statistics(sd: Dict[str, np.ndarray], mean: np.ndarray, var: np.ndarray) -> Dict[str, np.ndarray]:
+    """Copy of ``sd`` whose final BatchNorm1d (``bn``, face_model.py:92) carries the given running statistics.
+
+    In a trained network those statistics ARE the mean and variance of the ``linear`` layer's output over the
+    data, so embeddings are spread over the sphere.  With random weights and random statistics every input lands
+    near one common direction; the verification protocol then subtracts that direction (Evaluation.py:84-89) and
+    what is left is small, which magnifies storage rounding by an order of magnitude -- a property of untrained
+    weights, not of the arithmetic under test.  Measure mean / var of the ``linear`` output on sample crops (any
+    implementation of the network will do) and pass them here to get weights that behave like trained ones."""
+    out = dict(sd)
+    out["bn.running_mean"] = np.asarray(mean, dtype=np.float32).copy()
+    out["bn.running_var"] = np.maximum(np.asarray(var, dtype=np.float32), 1e-6).copy()
+    return out
+
+
 def make_crops(batch: int, seed: int = 0, quantised: bool = True) -> np.ndarray:
     """f32 [batch,3,112,112] in [-1,1], as ToTensor + Normalize(0.5,0.5) would give.
 

@@ -32,8 +32,8 @@ PHASE_PAIRS = {"LFW": 6000, "CFP_FP": 7000, "AgeDB30": 6000}   # dataloader.py:2
 
 class SyntheticPairs:
     """Stand-in for the reference's LFW / CFP_FP / AgeDB30 datasets (``dataloader.py:22-160``): ``folds``,
-    ``flags`` and items of four crops.  Batches are a function of (seed, first pair, batch size) only, so
-    any batch can be produced on its own, on the device that will embed it."""
+    ``flags`` and items of four crops.  A pair's crops are a function of (seed, pair index) only, so any batch
+    can be produced on its own, at any batch size, on the device that will embed it."""
 
     def __init__(self, pairs: int, seed: int = 0, noise: float = 0.45, device=None):
         ps = synthetic.PairSet(pairs)
@@ -44,17 +44,28 @@ class SyntheticPairs:
     def __len__(self) -> int:
         return self.pairs
 
-    def batch(self, start: int, size: int):
-        """[L, flip(L), R, flip(R)] for pairs start .. start+size-1, f32 [size,3,112,112]."""
-        n = min(size, self.pairs - start)
+    CHUNK = 10     # pairs are generated in fixed chunks, so a pair's crops do not depend on the batch size it is served in
+
+    def _chunk(self, c: int):
+        first = c * self.CHUNK
+        n = min(self.CHUNK, self.pairs - first)
         g = torch.Generator(device=self.device)
-        g.manual_seed(self.seed * 1_000_003 + start)
+        g.manual_seed(self.seed * 1_000_003 + c)
         up = lambda t: t.repeat_interleave(8, 2).repeat_interleave(8, 3)    # noqa: E731
         t1 = up(torch.rand((n, 3, 14, 14), generator=g, device=self.device) * 2 - 1)
         t2 = up(torch.rand((n, 3, 14, 14), generator=g, device=self.device) * 2 - 1)
-        same = torch.tensor(self.flags[start:start + n], device=self.device).view(-1, 1, 1, 1) == 1
+        same = torch.tensor(self.flags[first:first + n], device=self.device).view(-1, 1, 1, 1) == 1
         left = (t1 + self.noise * torch.randn(t1.shape, generator=g, device=self.device)).clamp_(-1, 1)
         right = (torch.where(same, t1, t2) + self.noise * torch.randn(t1.shape, generator=g, device=self.device)).clamp_(-1, 1)
+        return left, right
+
+    def batch(self, start: int, size: int):
+        """[L, flip(L), R, flip(R)] for pairs start .. start+size-1, f32 [size,3,112,112]."""
+        end = min(start + size, self.pairs)
+        parts = [self._chunk(c) for c in range(start // self.CHUNK, (end - 1) // self.CHUNK + 1)]
+        lo = start - (start // self.CHUNK) * self.CHUNK
+        left = torch.cat([p[0] for p in parts])[lo:lo + end - start].contiguous()
+        right = torch.cat([p[1] for p in parts])[lo:lo + end - start].contiguous()
         return [left, torch.flip(left, dims=[3]), right, torch.flip(right, dims=[3])]   # cv2.flip(img, 1): dataloader.py:60
 
 

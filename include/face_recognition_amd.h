@@ -165,8 +165,12 @@ int mfn_op_linear_l2norm(int dtype, const void* in, const void* wExK, const floa
 int fb_create(fb_handle** out, int device, const float* gallery, int gallery_is_device, int64_t N, int D,
               int store_dtype, int64_t index_base);
 /* Write rows [row0, row0+n) of a gallery created with gallery == NULL (or overwrite rows); lets a
- * large shard be produced piecewise on the device.  Synchronous. */
+ * large shard be produced piecewise on the device.  Synchronous; runs on a stream of the handle's own, so device
+ * rows must be complete when it is called (synchronise their producer stream first) and no other stream is stalled. */
 int fb_fill(fb_handle* h, int64_t row0, const float* rows, int rows_is_device, int64_t n);
+/* fb_fill for device rows, queued on `stream` and not waited for: searches queued on the same stream afterwards see
+ * the rows; rows_dev must stay valid until the stream reaches that point. */
+int fb_fill_async(fb_handle* h, int64_t row0, const float* rows_dev, int64_t n, fra_stream stream);
 int64_t fb_rows(const fb_handle* h);
 /* Packed form of rows [row0, row0+n) of a 16-bit gallery: the 16-bit rows [n,D] and the fp32 bias terms
  * -|g|^2/2 [n] exactly as the search kernel reads them.  Export after fb_fill and import into a gallery

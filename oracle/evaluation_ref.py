@@ -47,9 +47,14 @@ def get_threshold(scores, flags, thr_num, method) -> float:
 
 
 def evaluation_10_fold(feature_l: np.ndarray, feature_r: np.ndarray, folds, flags,
-                       method: str = "l2_distance", thr_num: int = 10000
+                       method: str = "l2_distance", thr_num: int = 10000, fixed_thresholds=None
                        ) -> Tuple[np.ndarray, np.ndarray]:
-    """Evaluation.py:68-99.  feature_*: f32 [P,D]; folds ints 0..9; flags +-1."""
+    """Evaluation.py:68-99.  feature_*: f32 [P,D]; folds ints 0..9; flags +-1.
+
+    ``fixed_thresholds`` (not in the reference; a test aid): ten per-fold thresholds to score the test folds
+    with instead of the ones searched on the validation folds -- "accuracy at the reference's threshold".  The
+    searched threshold is the mean of a plateau of equally good grid points and jumps when a tie between two
+    plateaus breaks, so comparing accuracies at each side's OWN thresholds measures that jump, not the features."""
     accs = np.zeros(10)
     threshold = np.zeros(10)
     fold = np.array(folds).reshape(1, -1)
@@ -72,7 +77,10 @@ def evaluation_10_fold(feature_l: np.ndarray, feature_r: np.ndarray, folds, flag
             scores = np.sum(np.multiply(fl, fr), 1)                            # :94
         else:
             raise ValueError(method)
-        threshold[i] = get_threshold(scores[val[0]], flags[val[0]], thr_num, method)
+        if fixed_thresholds is not None:
+            threshold[i] = fixed_thresholds[i]
+        else:
+            threshold[i] = get_threshold(scores[val[0]], flags[val[0]], thr_num, method)
         accs[i] = get_accuracy(scores[test[0]], flags[test[0]], threshold[i], method)
     return accs, threshold
 

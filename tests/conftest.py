@@ -27,6 +27,23 @@ def state_dict_np():
 
 
 @pytest.fixture(scope="session")
+def calibrated_state_dict_np(state_dict_np):
+    """The seeded weights with the final BatchNorm1d's running statistics set to what the `linear` layer actually
+    outputs on sample crops (measured with the CPU oracle), as they are in a trained network: embeddings then spread
+    over the sphere instead of clustering around one direction (synthetic.with_embedding_statistics)."""
+    import torch
+    from face_recognition_amd import synthetic
+    from oracle import mobilefacenet_ref
+    left, right, _ = synthetic.pair_crops(60, seed=99, noise=0.45)
+    taps = {}
+    mobilefacenet_ref.forward(state_dict_np, torch.from_numpy(np.concatenate([left, right])), taps)
+    y = taps["pre_norm"].numpy().astype(np.float64)
+    g, b, mu, var = (np.asarray(state_dict_np["bn." + k], dtype=np.float64) for k in ("weight", "bias", "running_mean", "running_var"))
+    z = (y - b) / g * np.sqrt(var + 1e-5) + mu              # the linear layer's output, from the BatchNorm's
+    return synthetic.with_embedding_statistics(state_dict_np, z.mean(0), z.var(0))
+
+
+@pytest.fixture(scope="session")
 def device():
     import torch
     if not torch.cuda.is_available():
@@ -40,6 +57,15 @@ def hip_model(device, state_dict_np):
     from face_recognition_amd.face_model import MobileFaceNet
     m = MobileFaceNet(512)
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state_dict_np.items()})
+    return m.to(device).eval()
+
+
+@pytest.fixture(scope="session")
+def hip_model_calibrated(device, calibrated_state_dict_np):
+    import torch
+    from face_recognition_amd.face_model import MobileFaceNet
+    m = MobileFaceNet(512)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in calibrated_state_dict_np.items()})
     return m.to(device).eval()
 
 
