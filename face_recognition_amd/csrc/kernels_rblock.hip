@@ -26,6 +26,7 @@
 // A band of TR < H rows (one block per launch) runs the same arithmetic per output value -- the same MFMA
 // shapes, operand order and roundings -- so results do not depend on which configuration a batch size selects.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -402,6 +403,9 @@ static int launch_rblock_t(int c, int cexp, int h, const void* x, const void* wp
 
 bool rblock_chain_pays(int c, int cexp, int h, int B) {
     // whole-image workgroups: worth it once they fill more of the chip than two-band workgroups would
+    // (FRA_RB_CHAIN_MIN=<batch> moves the limit, for measurements)
+    static const int min_b = [] { const char* e = getenv("FRA_RB_CHAIN_MIN"); return e ? atoi(e) : 0; }();
+    if (min_b > 0) return c == 128 && cexp == 256 && h == 14 && B >= min_b;
     return c == 128 && cexp == 256 && h == 14 && (int64_t)B * 2 > rb_compute_units();
 }
 
