@@ -35,14 +35,14 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 //              { WAIT fragment n; two MFMAs; issue fragment n + 4 }.
 // dw_outstanding() replays that order and returns the number of reads issued after the awaited one.
 constexpr int DW_STEPS = 20, DW_PD = 2, DW_RING = DW_PD + 1;   // reads run DW_PD steps ahead (3 measured no faster)
-constexpr int dw_outstanding(int nt16, int nq, int kind, int st, int n) {   // kind 0: taps(st); kind 1: fragment n in step st
+constexpr int dw_outstanding(int nt16, int nq, int kind, int st, int n, int nsub = 2) {   // kind 0: taps(st); kind 1: fragment n in step st; nsub: tap reads per step
     int issued = 7;
     int taps_idx[DW_STEPS] = {};
     int a3_idx[64] = {};
-    for (int i = 0; i < DW_PD; ++i) { issued += 2; taps_idx[i] = issued - 1; }
+    for (int i = 0; i < DW_PD; ++i) { issued += nsub; taps_idx[i] = issued - 1; }
     for (int ST = 0; ST < 5 * nq; ++ST) {
         const int q = ST / 5, p = ST % 5;
-        if (ST + DW_PD < 5 * nq) { issued += 2; taps_idx[ST + DW_PD] = issued - 1; }
+        if (ST + DW_PD < 5 * nq) { issued += nsub; taps_idx[ST + DW_PD] = issued - 1; }
         if ((q & 1) && p == 2)
             for (int i = 0; i < cmin(4, nt16); ++i) { issued += 1; a3_idx[i] = issued - 1; }
         if (kind == 0 && st == ST) return cmin(issued - 1 - taps_idx[ST], 15);
@@ -90,15 +90,16 @@ template <int H, int S> constexpr int block_pitch() {
 // chunk pair (k = 8 g + j: j < 4 from the even chunk, j >= 4 from the odd one; the project weights are
 // stored in that order when their slice is staged).
 // NQ: chunks of the slice this wave handles (4, or 2 = one chunk pair when two waves share a tile)
-template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ> struct DwStage {
+// NSUB: 16-pixel subtiles this wave handles (2, or 1 when two waves share a tile: `tb` then points at the wave's subtile)
+template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ, int NSUB = 2> struct DwStage {
     typedef typename vec8<T>::type V8;
-    V8 er[DW_RING][2];             // ring: image unit of a tap pair, per subtile
+    V8 er[DW_RING][NSUB];          // ring: image unit of a tap pair, per subtile
     V8 a3[4];                      // ring: project fragments
     uint32_t w16[5];               // this lane's depthwise weight of each tap pair (16 bits)
     uint32_t msk[4];               // where that weight sits inside the diagonal fragment (all zero for half the lanes)
     f32x4 bias, slope;
-    f32x4 acc[2];
-    V8 bf[2];                      // project B operand of the chunk pair, per subtile
+    f32x4 acc[NSUB];
+    V8 bf[NSUB];                   // project B operand of the chunk pair, per subtile
     // LDS address of this lane's unit in subtile 0: [0] tap 0 / 1 (pairs 0, 1, 2 are 0, 1, 2 image rows = ROWB bytes
     // further), [1] tap 5 / 2 (pair 4 is one row further: tap 8, and for the odd half tap 5's slot with a zero weight);
     // + ST1 for subtile 1; + 32 q
@@ -111,7 +112,7 @@ template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ> st
         constexpr int q = ST / 5, p = ST % 5;
         constexpr int off = (p < 3 ? p : p - 3) * ROWB + 32 * q;
         LDS_READ16(er[ST % DW_RING][0], tb[p < 3 ? 0 : 1], off);
-        LDS_READ16(er[ST % DW_RING][1], tb[p < 3 ? 0 : 1], ST1 + off);
+        if constexpr (NSUB == 2) LDS_READ16(er[ST % DW_RING][1], tb[p < 3 ? 0 : 1], ST1 + off);
     }
     template <int Q, int P> __device__ __forceinline__ void issue_w16() {
         // pairs 0..2: rows 3 P (+1 for the odd half); pair 3: rows 5 / 9 (tap 5 / a copy of tap 2); pair 4: three rows further, tap 8 / the zero row 12
@@ -133,11 +134,11 @@ template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ> st
     template <int ST> __device__ __forceinline__ void preamble_taps() {
         if constexpr (ST < DW_PD) { issue_taps<ST>(); preamble_taps<ST + 1>(); }
     }
-    template <int ST, int PAIR, int N = 0> __device__ __forceinline__ void project(f32x4 (&pacc)[2][NT16]) {
+    template <int ST, int PAIR, int N = 0> __device__ __forceinline__ void project(f32x4 (&pacc)[NSUB][NT16]) {
         if constexpr (N < NT16) {
-            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a3[N & 3]) : "n"(dw_outstanding(NT16, NQ, 1, ST, N)));
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a3[N & 3]) : "n"(dw_outstanding(NT16, NQ, 1, ST, N, NSUB)));
             pacc[0][N] = mfma16(a3[N & 3], bf[0], pacc[0][N]);
-            pacc[1][N] = mfma16(a3[N & 3], bf[1], pacc[1][N]);
+            if constexpr (NSUB == 2) pacc[1][N] = mfma16(a3[N & 3], bf[1], pacc[1][N]);
             if constexpr (N + 4 < NT16) {
                 __builtin_amdgcn_sched_barrier(0);         // the ring slot is free once both MFMAs are issued
                 issue_a3<PAIR, N + 4>();
@@ -146,21 +147,17 @@ template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ> st
             project<ST, PAIR, N + 1>(pacc);
         }
     }
-    template <int ST = 0> __device__ __forceinline__ void run(f32x4 (&pacc)[2][NT16]) {
+    template <int ST = 0> __device__ __forceinline__ void run(f32x4 (&pacc)[NSUB][NT16]) {
         if constexpr (ST < 5 * NQ) {
             constexpr int q = ST / 5, p = ST % 5, slot = ST % DW_RING;
             if constexpr (ST + DW_PD < 5 * NQ) issue_taps<ST + DW_PD>();
             if constexpr ((q & 1) && p == 2) issue_a3_first<(q >> 1)>();
             // everything issued before taps(ST) has landed with them: w16[p], bias (p == 0), slope (p == 4)
-            if constexpr (p == 0)
-                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(er[slot][0]), "+v"(er[slot][1]), "+v"(w16[p]), "+v"(bias)
-                             : "n"(dw_outstanding(NT16, NQ, 0, ST, 0)));
-            else if constexpr (p == 4)
-                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(er[slot][0]), "+v"(er[slot][1]), "+v"(w16[p]), "+v"(slope)
-                             : "n"(dw_outstanding(NT16, NQ, 0, ST, 0)));
-            else
-                asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(er[slot][0]), "+v"(er[slot][1]), "+v"(w16[p])
-                             : "n"(dw_outstanding(NT16, NQ, 0, ST, 0)));
+            constexpr int OUT = dw_outstanding(NT16, NQ, 0, ST, 0, NSUB);
+            if constexpr (NSUB == 2) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(er[slot][0]), "+v"(er[slot][1]), "+v"(w16[p]) : "n"(OUT));
+            else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(er[slot][0]), "+v"(w16[p]) : "n"(OUT));
+            if constexpr (p == 0) asm volatile("" : "+v"(bias));      // volatile statements keep their order: uses come after the wait
+            if constexpr (p == 4) asm volatile("" : "+v"(slope));
             const uint32_t wd = w16[p] | (w16[p] << 16);
             const u32x4 du = {wd & msk[0], wd & msk[1], wd & msk[2], wd & msk[3]};
             const V8 dg = __builtin_bit_cast(V8, du);
@@ -170,18 +167,18 @@ template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ> st
             }
             if constexpr (p == 0) {
                 acc[0] = mfma16(dg, er[slot][0], bias);
-                acc[1] = mfma16(dg, er[slot][1], bias);
+                if constexpr (NSUB == 2) acc[1] = mfma16(dg, er[slot][1], bias);
                 if constexpr (q + 1 < NQ) {
                     __builtin_amdgcn_sched_barrier(0);
                     issue_bias<q + 1>();
                 }
             } else {
                 acc[0] = mfma16(dg, er[slot][0], acc[0]);
-                acc[1] = mfma16(dg, er[slot][1], acc[1]);
+                if constexpr (NSUB == 2) acc[1] = mfma16(dg, er[slot][1], acc[1]);
             }
             if constexpr (p == 4) {
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+                for (int s = 0; s < NSUB; ++s)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float d = acc[s][i];

@@ -143,6 +143,10 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     constexpr int MTIP = MTI > 2 ? 4 : (MTI > 1 ? 2 : 1);
     static_assert(CEXP % 128 == 0 && C % 32 == 0 && H % TR == 0, "shape");
     static_assert(MTO <= NW, "one output tile per wave");
+    // with at most NW / 4 main tiles the two waves that share an input tile also share its depthwise / project work:
+    // one 16-pixel subtile each (pixels are columns of every product, so nothing about a value changes)
+    constexpr bool SSPLIT = ESPLIT && 4 * MTO <= NW;
+    constexpr int NSUB = SSPLIT ? 1 : 2;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(LDS_BYTES == rblock_lds_bytes<C, CEXP, H, TR>(), "the launcher's LDS size is this map's");
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -218,19 +222,20 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
                 }
     };
 
-    // ---- depthwise / project side: wave wt owns output tile wt (its own main input tile) ----------------------
-    const int wt = wave;
-    const bool dw_active = wt < MTO;
+    // ---- depthwise / project side: wave wt owns output tile wt (its own main input tile), or one subtile of it --
+    const int wt = SSPLIT ? we : wave;
+    const bool dw_active = SSPLIT ? (we < MTO && en < 2) : (wt < MTO);
     constexpr int ST1 = POW == 32 ? 16 * SLOT : (16 / POW) * PITCH * SLOT;
     static_assert(ST1 + 2 * PITCH * SLOT + 96 < 65536, "tap offsets must fit the instruction's offset field");
     int tb[2];            // LDS byte address of unit (g >> 1) of tap 0 / 1 and of tap 5 / 2 (DwStage::tb)
     {
         const int oy = wt * RPT + m16 / POW, ox = m16 % POW;
         const int h1 = g4 & 1;
-        tb[0] = (oy * PITCH + ox + h1) * SLOT + 16 * (g4 >> 1);                // tap 0 = (0,0) / tap 1 = (0,1)
-        tb[1] = ((oy + 1 - h1) * PITCH + ox + 2) * SLOT + 16 * (g4 >> 1);      // tap 5 = (1,2) / tap 2 = (0,2)
+        const int sub = SSPLIT ? en * ST1 : 0;                                 // (SSPLIT) this wave's subtile
+        tb[0] = (oy * PITCH + ox + h1) * SLOT + 16 * (g4 >> 1) + sub;          // tap 0 = (0,0) / tap 1 = (0,1)
+        tb[1] = ((oy + 1 - h1) * PITCH + ox + 2) * SLOT + 16 * (g4 >> 1) + sub;  // tap 5 = (1,2) / tap 2 = (0,2)
     }
-    f32x4 pacc[2][NT16];  // tile n of subtile st, register i <-> output channel 16 n + 4 g + i
+    f32x4 pacc[NSUB][NT16];  // tile n of subtile st, register i <-> output channel 16 n + 4 g + i
 
     auto expand = [&](int buf) {
         if (we >= MTI || en >= 2) return;                  // wave-uniform
@@ -251,7 +256,7 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     auto dwproject = [&](int buf) {
         if (!dw_active) return;                            // wave-uniform
         const int base = ES_BYTES + buf * PK::BYTES;
-        DwStage<T, 64, NT16, PK::PW3, ST1, PITCH * SLOT, 4> dw;
+        DwStage<T, 64, NT16, PK::PW3, ST1, PITCH * SLOT, 4, NSUB> dw;
         dw.tb[0] = tb[0];
         dw.tb[1] = tb[1];
 #pragma unroll
@@ -277,7 +282,7 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
 #pragma unroll 1
         for (int b = 0; b < nblk; ++b) {
 #pragma unroll
-            for (int st = 0; st < 2; ++st)
+            for (int st = 0; st < NSUB; ++st)
 #pragma unroll
                 for (int n = 0; n < NT16; ++n) pacc[st][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -306,28 +311,35 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
                     bq3.issue(ES_BYTES + buf * PK::BYTES + PK::OFF_B3 + 16 * g4);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     bq3.pin();
-#pragma unroll
-                    for (int st = 0; st < 2; ++st)
+                    // subtile st of the tile, accumulated in pacc[a]
+                    auto finish = [&](auto st_c, auto a_c) {
+                        constexpr int st = decltype(st_c)::value, a = decltype(a_c)::value;
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
                                 const int n = 2 * ks + (j >> 2), i = j & 3;
-                                const float v = pacc[st][n][i] + (float)xf[0][st][ks][j];
+                                const float v = pacc[a][n][i] + (float)xf[0][st][ks][j];
                                 xf[0][st][ks][j] = (T)(v + bq3.q[n][i]);
                             }
-                    if (b == nblk - 1) {
-                        T* Oimg = O + (size_t)img * H * W * C;
+                        if (b == nblk - 1 && lds_px[0][st] >= 0) {
+                            T* Oimg = O + (size_t)img * H * W * C;
 #pragma unroll
-                        for (int st = 0; st < 2; ++st)
-                            if (lds_px[0][st] >= 0) {
-#pragma unroll
-                                for (int ks = 0; ks < KS; ++ks) {
-                                    const V8 v = xf[0][st][ks];
-                                    *reinterpret_cast<V4*>(Oimg + x_off[0][st] + 32 * ks) = V4{v[0], v[1], v[2], v[3]};
-                                    *reinterpret_cast<V4*>(Oimg + x_off[0][st] + 32 * ks + 16) = V4{v[4], v[5], v[6], v[7]};
-                                }
+                            for (int ks = 0; ks < KS; ++ks) {
+                                const V8 v = xf[0][st][ks];
+                                *reinterpret_cast<V4*>(Oimg + x_off[0][st] + 32 * ks) = V4{v[0], v[1], v[2], v[3]};
+                                *reinterpret_cast<V4*>(Oimg + x_off[0][st] + 32 * ks + 16) = V4{v[4], v[5], v[6], v[7]};
                             }
+                        }
+                    };
+                    typedef std::integral_constant<int, 0> I0;
+                    typedef std::integral_constant<int, 1> I1;
+                    if constexpr (SSPLIT) {
+                        if (en == 0) finish(I0{}, I0{});       // wave-uniform
+                        else finish(I1{}, I0{});
+                    } else {
+                        finish(I0{}, I0{});
+                        finish(I1{}, std::integral_constant<int, NSUB - 1>{});
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

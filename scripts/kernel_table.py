@@ -1,13 +1,18 @@
-"""Prints the per-kernel table (event and rocprofv3 durations, algorithmic and measured bytes, GB/s, TFLOP/s) from profiles/r01_bench.json, r01_kernel_stats.csv and r01_pmc_traffic.json."""
-import csv, json, os, re
+"""Prints the per-kernel table (event and rocprofv3 durations, algorithmic and measured bytes, GB/s, TFLOP/s) from
+profiles/<tag>_bench.json, <tag>_kernel_stats.csv and <tag>_pmc_traffic.json:  python scripts/kernel_table.py [tag, default r02]"""
+import csv, json, os, re, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-r = json.load(open(os.path.join(root, "profiles/r01_bench.json")))
-tr = json.load(open(os.path.join(root, "profiles/r01_pmc_traffic.json")))["kernels"]
+r = json.load(open(os.path.join(root, f"profiles/{tag}_bench.json")))
+tr = json.load(open(os.path.join(root, f"profiles/{tag}_pmc_traffic.json")))["kernels"]
 st = {}
-for row in csv.DictReader(open(os.path.join(root, "profiles/r01_kernel_stats.csv"))):
+for row in csv.DictReader(open(os.path.join(root, f"profiles/{tag}_kernel_stats.csv"))):
     n = row["Name"]
-    m = re.search(r"block_kernelIDF16_Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", n)
-    if m and int(m.group(6)) in (4, 7, 14):      # the tall-band configurations a full batch runs
+    mr = re.search(r"rblock_kernelIDF16_Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", n)
+    m = None if mr else re.search(r"block_kernelIDF16_Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", n)
+    if mr and mr.group(3) == mr.group(4):        # whole-image workgroups: the chained launch a full batch runs
+        st["rblock_kernel<_Float16, %s, %s, %s>" % mr.groups()[:3]] = float(row["AverageNs"]) / 1e3
+    elif m and int(m.group(6)) in (4, 7, 14):      # the tall-band configurations a full batch runs
         st["block_kernel<_Float16, %s, %s, %s, %s, %s>" % m.groups()[:5]] = float(row["AverageNs"]) / 1e3
     elif "stemdw_kernelIDF16_" in n: st["stemdw_kernel<_Float16>"] = float(row["AverageNs"]) / 1e3
     elif "tail_kernelIDF16_" in n: st["tail_kernel<_Float16>"] = float(row["AverageNs"]) / 1e3
@@ -15,6 +20,7 @@ for row in csv.DictReader(open(os.path.join(root, "profiles/r01_kernel_stats.csv
         st["linear_l2norm_kernel<_Float16, 16, 1>"] = st.get("linear_l2norm_kernel<_Float16, 16, 1>", 0.0) + float(row["AverageNs"]) / 1e3
 names = {"block_kernel<_Float16, 64, 128, 64, 28, 1>": "`block_kernel` 64â†’128â†’64 @28Â², s1 (conv_3, Ã—4)",
          "block_kernel<_Float16, 128, 256, 128, 14, 1>": "`block_kernel` 128â†’256â†’128 @14Â², s1 (conv_4, Ã—6)",
+         "rblock_kernel<_Float16, 128, 256, 14>": "`rblock_kernel` 128â†’256â†’128 @14Â², s1 (conv_4: six blocks, ONE launch)",
          "block_kernel<_Float16, 64, 128, 64, 56, 2>": "`block_kernel` 64â†’128â†’64 @56Â², s2 (conv_23, Ã—1)",
          "stemdw_kernel<_Float16>": "`stemdw_kernel` (conv1 + conv2_dw, Ã—1)",
          "block_kernel<_Float16, 64, 256, 128, 28, 2>": "`block_kernel` 64â†’256â†’128 @28Â², s2 (conv_34, Ã—1)",
@@ -25,7 +31,7 @@ names = {"block_kernel<_Float16, 64, 128, 64, 28, 1>": "`block_kernel` 64â†’128â
 tb = tt = ts = 0.0
 for k, v in sorted(r["kernels"].items(), key=lambda kv: -kv[1]["ms"]):
     alg = v["GBps"] * v["ms"] * 1e-3 * 1e9 / v["launches"] / 1e6
-    pm = tr[k]["hbm_bytes_per_launch"] / 1e6
+    pm = tr.get(k, {}).get("hbm_bytes_per_launch", float("nan")) / 1e6
     tb += alg * v["launches"]; tt += pm * v["launches"]; ts += st[k] * v["launches"]
     print("| %s | %.3f | %.1f | %.1f | %.0f | %.0f | %.0f |" % (names[k], v["ms"], st[k], alg, pm, v["GBps"], v["TFLOPs"]))
 print("| whole forward | %.2f (wall) | %.0f (sum) | %.1f GB | %.1f GB | %.2f TB/s | %.0f |"
@@ -33,5 +39,7 @@ print("| whole forward | %.2f (wall) | %.0f (sum) | %.1f GB | %.1f GB | %.2f TB/
 print(r["value"], r["ms_per_step"], r["roofline"])
 print({k: (v["eager_forward"]["p50"], v["graph_forward_match"]["p50"], v["graph_forward_match_bank5"]["p50"], v["graph_tta_forward_match"]["p50"]) for k, v in r["latency_us"].items()})
 print(r["search"]["value"], r["search"]["ms_per_batch"], r["search"]["roofline"]["frac"])
+print(r.get("search_1m"))
+print(r.get("roofline_by_class"))
 print(r["cpu_baseline"])
 print(r["other_call_shapes"], r["verification_12k_pairs"])
