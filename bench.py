@@ -490,6 +490,8 @@ def main():
             result["latency_us"] = latency(net, dev)
             result["verification_10fold"] = verification_timing(dev)
             result["verification_12k_pairs"] = verification_12k(net, dev)
+            # the reference harness's own batch size: 50 pairs = 200 crops per forward (test_lfw_agedb_cfpfp.py:60)
+            result["verification_12k_pairs_bs50"] = verification_12k(net, dev, batch=50)
     if not args.no_search:
         if world == 1:      # BASELINE configs[3]: 10k queries x 1M fp16 rows, top-5, one GPU
             result["search_1m"] = run_search(args, rank, world, dev, dist, total=1_000_000, check_sample=40)

@@ -451,6 +451,8 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
         }
     }
     FRA_DEVICE(h->device);
+    // a reload overwrites the arena forwards may still be reading (any stream): let the device drain first
+    if (h->loaded) FRA_HIP(hipDeviceSynchronize());
     if (h->arena_bytes < off) {
         if (h->arena) FRA_HIP(hipFree(h->arena));
         h->arena = nullptr;

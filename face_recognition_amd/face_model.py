@@ -331,7 +331,7 @@ class MobileFaceNet(nn.Module):
     def __del__(self):
         try:
             if getattr(self, "_handle", None) is not None:
-                _lib.load().mfn_destroy(self._handle)
+                _lib.load().mfn_destroy(self._handle)     # frees under a device guard of its own
                 self._handle = None
         except Exception:
             pass

@@ -55,7 +55,8 @@ int mfn_create(mfn_handle** out, int device, int embedding_size, int act_dtype);
 
 /* Load a state_dict (the 333 keys of face_model.py:80-92; "num_batches_tracked" entries may be
  * omitted; a leading "module." is ignored).  Folds every BatchNorm into the preceding conv /
- * linear layer (eps 1e-5), repacks to the kernels' layouts and uploads.  Synchronous.
+ * linear layer (eps 1e-5), repacks to the kernels' layouts and uploads.  Synchronous; a RE-load first waits for
+ * the device to drain, since forwards in flight on any stream still read the old weights.
  * Replaces Module.load_state_dict as used at cam_demo.py:52, Evaluation.py:110, facebank.py:88. */
 int mfn_load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n);
 

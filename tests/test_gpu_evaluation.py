@@ -144,3 +144,15 @@ def test_get_feature_on_device_feeds_device_10fold(hip_model, device):
     a_dev, t_dev = Evaluation.evaluation_10_fold(fl, fr, ds, "cos_distance")
     a_host, t_host = Evaluation.evaluation_10_fold(fl.cpu(), fr.cpu(), ds, "cos_distance")
     assert np.array_equal(a_dev, a_host) and np.array_equal(t_dev, t_host)
+
+
+def test_device_features_of_other_widths_take_the_host_path(device):
+    """embedding_size 1024 is a width the device scoring kernel does not take: evaluation_10_fold then runs the
+    reference's host arithmetic on a copy instead of failing."""
+    rng = np.random.default_rng(3)
+    ds = synthetic.PairSet(200)
+    fl = rng.standard_normal((200, 1024)).astype(np.float32)
+    fr = (fl + 0.8 * rng.standard_normal((200, 1024))).astype(np.float32)
+    a_dev, t_dev = Evaluation.evaluation_10_fold(torch.from_numpy(fl).to(device), torch.from_numpy(fr).to(device), ds, "cos_distance")
+    a_host, t_host = Evaluation.evaluation_10_fold(fl, fr, ds, "cos_distance")
+    assert np.array_equal(a_dev, a_host) and np.array_equal(t_dev, t_host)

@@ -184,6 +184,35 @@ def test_gallery_fill_piecewise(device):
     assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
 
 
+def test_fp32_search_in_query_chunks(device):
+    """An fp32 gallery's Q x N distance matrix is produced in chunks of queries (256 MB of scratch at most):
+    1100 x 70000 needs two chunks and must equal the brute force row for row."""
+    g = synthetic.unit_rows(70000, 512, seed=3)
+    q, _ = synthetic.planted_queries(g, 1100, seed=4)
+    d, i = topk_search(torch.from_numpy(q).to(device), torch.from_numpy(g).to(device), k=3, store="f32")
+    bd, bi = mref.l2_topk_bruteforce(q, g, 3)
+    assert np.array_equal(i.cpu().numpy(), bi)
+    assert np.allclose(d.cpu().numpy(), bd, rtol=1e-5, atol=3e-6)
+
+
+def test_fill_is_ordered_on_the_current_stream(device):
+    """Gallery.fill of device rows is queued on the current stream without waiting: rows written by kernels queued just
+    before it, on a side stream, are the rows a search queued after it finds."""
+    g = torch.from_numpy(synthetic.unit_rows(6000, 512, seed=3)).to(device)
+    gal = Gallery(None, n=6000, d=512, store="f16", device=device)
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        big = torch.randn((4096, 4096), device=device)
+        for _ in range(6):
+            big = big @ big * 1e-3                      # keeps the stream busy while the rows are produced behind it
+        rows = g * 1.0 + big[0, 0] * 0.0                # rows depend on the slow work
+        gal.fill(0, rows)
+        d, i = gal.search(g[[5, 4321]], 1)
+    side.synchronize()
+    assert i.cpu().flatten().tolist() == [5, 4321] and float(d.abs().max()) < 1e-3
+
+
 def test_facebank_errors(device):
     with pytest.raises(RuntimeError):
         Gallery(torch.zeros((4, 100)), store="f16", device=device)      # packed search needs D == 512
