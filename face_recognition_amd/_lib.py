@@ -71,6 +71,25 @@ SIGNATURES = {
 _lib: Optional[C.CDLL] = None
 
 
+def _preload_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 and may not have loaded them yet when this
+    library is.  Loaded on its own, this library would then pull in the system copies (/opt/rocm/lib), the process would
+    hold TWO HIP runtimes, and whichever initialises second reports "no ROCm-capable device".  Loading torch's copies
+    first makes the dynamic loader resolve this library's libamdhip64.so.N to them (same SONAME)."""
+    try:
+        import torch
+    except ImportError:
+        return
+    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def load() -> C.CDLL:
     """Load the shared object once and attach signatures.  Raises if it is not built."""
     global _lib
@@ -80,6 +99,7 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m face_recognition_amd.build` "
             "(hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it

@@ -40,6 +40,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-x", "hip", "-Wall", "-Wno-unused-function",
              # keep scalar f16*f16+f32 FMAs (v_fma_mix_f32) instead of convert + packed-f32 FMA
              "-fno-slp-vectorize"]
+    # the library alone travels to the GPU box (objects stay behind): when it is newer than every source, it is current
+    if not force and not _stale(LIB, [os.path.join(CSRC, src) for src in SOURCES] + headers):
+        return LIB
     jobs = []
     objs = []
     for src in SOURCES:
