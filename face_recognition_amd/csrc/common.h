@@ -16,6 +16,7 @@ typedef __bf16 bf16;
 
 template <typename T> struct vec8 { typedef T type __attribute__((ext_vector_type(8))); };
 template <typename T> struct vec4 { typedef T type __attribute__((ext_vector_type(4))); };
+template <typename T> struct vec16 { typedef T type __attribute__((ext_vector_type(16))); };
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -38,6 +39,13 @@ __device__ __forceinline__ f32x4 mfma16(vec8<f16>::type a, vec8<f16>::type b, f3
 }
 __device__ __forceinline__ f32x4 mfma16(vec8<bf16>::type a, vec8<bf16>::type b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// one sparse 16x16x64 MFMA step (A 2:4 structured: eight values per lane, their positions in `idx`), fp32 accumulate
+__device__ __forceinline__ f32x4 smfma16(vec8<f16>::type a, vec16<f16>::type b, f32x4 c, int idx) {
+    return __builtin_amdgcn_smfmac_f32_16x16x64_f16(a, b, c, idx, 0, 0);
+}
+__device__ __forceinline__ f32x4 smfma16(vec8<bf16>::type a, vec16<bf16>::type b, f32x4 c, int idx) {
+    return __builtin_amdgcn_smfmac_f32_16x16x64_bf16(a, b, c, idx, 0, 0);
 }
 // min(v, 0) as ONE instruction: the median of (v, 0, a huge negative number).  fminf() costs two (IEEE minimum
 // first quietens a signalling NaN with a v_max v, v); activations here are finite and far above -3e38.
@@ -162,15 +170,22 @@ int launch_block(int dt, const BlockParams& p, const void* x, void* out, int B, 
 //   of k-step ks, k-group g is INPUT channel rb_in_channel(ks, g, j) -- the order in which a lane of the project
 //   stage holds its output channels, so that a block's output is the next block's expand operand as it stands.
 // b1, s1 (slope - 1): natural channel order inside the slice.  Position of expanded channel 16 t + 4 g + i of the
-// slice on the depthwise / project side: 16 g + 4 t + i (rb_pos); b2, s2, the 3x3 weight image (13 rows of
-// 64 positions + 32 bytes: taps 0..8, tap 2 again, three zero rows) and the W3 image's columns use positions.
+// slice on the depthwise / project side: 16 g + 4 t + i (rb_pos); b2, s2, the 3x3 weight image (dw_wimage_bytes(64))
+// and the W3 image's columns use positions.
 // W3 image: 2 C rows of 64 + 16 bytes; row 32 n + 16 (g & 1) + m holds, for output channel 16 n + m, units
 // [pair P][g >> 1]; element j of a unit is position 32 P + 4 g + j (j < 4) or 32 P + 16 + 4 g + (j - 4).
+// ---- the 3x3 weight image of the fused block kernels in LDS -------------------------------------------------
+// One row per window row p of two planes: plane 0 holds, per expanded-channel position, the 32-bit word
+// tap (p,0) | tap (p,1) << 16, plane 1 the word tap (p,2) (upper half zero).  A plane is `ch` words + 16, so
+// that the two planes a wave's 32-bit read touches sit on different banks.
+constexpr int dw_wplane(int ch) { return ch * 4 + 64; }
+constexpr int dw_wrow(int ch) { return 2 * dw_wplane(ch); }
+constexpr int dw_wimage_bytes(int ch) { return 3 * dw_wrow(ch); }
 template <int C> struct RbPkg {
     static constexpr int PW1 = C + 16, W1_BYTES = 128 * PW1;
     static constexpr int PW3 = 80, W3_BYTES = 2 * C * PW3, OFF_W3 = W1_BYTES;
     static constexpr int OFF_B1 = OFF_W3 + W3_BYTES, OFF_S1 = OFF_B1 + 256, OFF_B2 = OFF_S1 + 256, OFF_S2 = OFF_B2 + 256;
-    static constexpr int PW2 = 160, OFF_W2 = OFF_S2 + 256, OFF_B3 = OFF_W2 + 13 * PW2;
+    static constexpr int OFF_W2 = OFF_S2 + 256, OFF_B3 = OFF_W2 + dw_wimage_bytes(64);
     static constexpr int RAW = OFF_B3 + C * 4;
     static constexpr int BYTES = (RAW + 1023) / 1024 * 1024, PIECES = BYTES / 1024;
 };

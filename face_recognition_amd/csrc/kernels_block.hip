@@ -10,8 +10,8 @@
 //   2. writes PReLU(expand) as 16-bit values into an LDS image [row][x+1][64 ch] whose border
 //      columns and out-of-image rows stay zero (that IS the depthwise conv's zero padding),
 //   3. runs the 3x3 depthwise conv on the matrix cores as well: per 16-channel chunk and 16-pixel
-//      subtile five 16x16x32 MFMAs whose A operand carries the weights of two taps on its diagonal
-//      and whose B operand is one 16-byte unit of the LDS image per lane.  Bias enters as the C
+//      subtile three sparse 16x16x64 MFMAs whose A operand carries the weights of a window row on its
+//      diagonal and whose B operand is two 16-byte units of the LDS image per lane.  Bias enters as the C
 //      operand; after PReLU and rounding a lane's four values are its share of the project MFMA's
 //      B operand -- the depthwise output never exists in memory at all.
 // Project accumulators live in registers across slices.  The epilogue turns them into rows of
@@ -125,7 +125,6 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     constexpr int P32 = COUT * 4 + 16;                     // epilogue staging: f32 pixel rows, padded
     constexpr int EPI1 = POUT * P32;                       // one set of staging rows
     constexpr int EPI_BYTES = KSPLIT * EPI1;               // overlays the image and weight buffer 1
-    constexpr int PW2 = CEXP * 2 + 32;                     // 3x3 weight rows, padded so that the two taps of a pair sit on different banks
     // LDS map: image | weight buffer 1 (odd slices) | per-channel parameters | 3x3 weights | weight buffer 0 (even
     // slices).  The epilogue's staging rows overlay the image and buffer 1 only: buffer 0 can receive the next
     // image's first slice while this image's last slice and epilogue still run.
@@ -133,7 +132,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     constexpr int OFF_PAR = (cmax(OFF_WB1 + WB_BYTES, EPI_BYTES) + 15) / 16 * 16;
     constexpr int OFF_B1 = OFF_PAR, OFF_S1 = OFF_B1 + CEXP * 4, OFF_B2 = OFF_S1 + CEXP * 4, OFF_S2 = OFF_B2 + CEXP * 4,
                   OFF_W2 = OFF_S2 + CEXP * 4;
-    constexpr int OFF_WB0 = OFF_W2 + 13 * PW2;             // 3x3 weights: rows 0..8 the taps, 9 tap 2 again, 10..12 zero
+    constexpr int OFF_WB0 = OFF_W2 + dw_wimage_bytes(CEXP);   // 3x3 weight image (common.h)
     constexpr int LDS_BYTES = OFF_WB0 + WB_BYTES;
     constexpr int CH1 = CIN / 8;
     // a weight slice arrives by LDS-DMA in pieces of 64 lanes x 16 bytes = 1 KB of the padded LDS image
@@ -202,11 +201,12 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         reinterpret_cast<f32x4*>(lds + OFF_B2)[i] = reinterpret_cast<const f32x4*>(b2p)[i];
         reinterpret_cast<f32x4*>(lds + OFF_S2)[i] = reinterpret_cast<const f32x4*>(s2p)[i];
     }
-    for (int i = tid; i < 13 * CEXP / 8; i += NT) {
-        const int row = i / (CEXP / 8), col = i - row * (CEXP / 8);
-        const int src = row == 9 ? 2 : row;
-        *reinterpret_cast<u32x4*>(lds + OFF_W2 + row * PW2 + col * 16) =
-            row < 10 ? reinterpret_cast<const u32x4*>(W2p)[src * (CEXP / 8) + col] : u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < 3 * CEXP; i += NT) {             // 3x3 weight image: window row, position -> its two words
+        const int row = i / CEXP, pos = i - row * CEXP;
+        const uint16_t* w2 = reinterpret_cast<const uint16_t*>(W2p) + 3 * row * CEXP + pos;
+        char* dst = lds + OFF_W2 + row * dw_wrow(CEXP) + pos * 4;
+        *reinterpret_cast<uint32_t*>(dst) = (uint32_t)w2[0] | ((uint32_t)w2[CEXP] << 16);
+        *reinterpret_cast<uint32_t*>(dst + dw_wplane(CEXP)) = (uint32_t)w2[2 * CEXP];
     }
 
     // ---- input fragments (B operand of the expand GEMM), resident while an image's slices are expanded -------
@@ -244,8 +244,8 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     // depthwise and the project product), and that column is never stored.
     constexpr int ST1 = POW == 32 ? 16 * S * SLOT : (16 / POW) * S * PITCH * SLOT;
     static_assert(ST1 + 96 < 65536, "subtile offset must fit the instruction's offset field");
-    static_assert(ST1 + 2 * S * PITCH * SLOT + 96 < 65536, "tap offsets must fit the instruction's offset field");
-    int tb[2];            // LDS byte address of unit (g >> 1) of tap 0 / 1 and of tap 5 / 2 (see DwStage::tb)
+    static_assert(ST1 + 2 * PITCH * SLOT + 112 < 65536, "tap offsets must fit the instruction's offset field");
+    int tb;               // LDS byte address of this lane's tap (0, min(g, 2)) (see DwStage::tb)
     bool out_ok[2];
     int po0;              // this lane's pixel of subtile 0 inside the band; subtile 1 is PO1 further
     constexpr int PO1 = POW == 32 ? 16 : (16 / POW) * Wo;
@@ -254,9 +254,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         po0 = oy * Wo + ox;
         out_ok[0] = (ox < Wo) && (oy < TR);
         out_ok[1] = POW == 32 ? (ox + 16 < Wo) && (oy < TR) : (ox < Wo) && (oy + 16 / POW < TR);
-        const int h1 = g4 & 1;
-        tb[0] = ((oy * S) * PITCH + ox * S + h1) * SLOT + 16 * (g4 >> 1);              // tap 0 = (0,0) / tap 1 = (0,1)
-        tb[1] = ((oy * S + 1 - h1) * PITCH + ox * S + 2) * SLOT + 16 * (g4 >> 1);      // tap 5 = (1,2) / tap 2 = (0,2)
+        tb = ((oy * S) * PITCH + ox * S + (g4 < 2 ? g4 : 2)) * SLOT;
     }
     // project accumulators: tile n of subtile st, register i <-> output channel 16 n + 4 g + i; the bias joins in the epilogue
     f32x4 pacc[2][NT16];
@@ -312,15 +310,9 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         if (!dw_active) return;                            // wave-uniform
         DwStage<T, CEXP, NT16, PW3, ST1, PITCH * SLOT, 4 / KSPLIT> dw;
         // a wave that takes chunk pair kp of the slice starts 2 kp chunks further in every per-chunk array
-        dw.tb[0] = tb[0] + eb * ES_BYTES + 64 * kp;
-        dw.tb[1] = tb[1] + eb * ES_BYTES + 64 * kp;
-        // diagonal fragment: element j of register pair j >> 1 is non-zero where channel 8 (g >> 1) + j is this lane's row
-        // (rebuilt per slice from the lane index: four registers that need not live through the expand stage)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            dw.msk[i] = ((m16 >> 3) == (g4 >> 1) && ((m16 & 7) >> 1) == i) ? ((m16 & 1) ? 0xFFFF0000u : 0x0000FFFFu) : 0u;
-        dw.w2l[0] = OFF_W2 + (g4 & 1) * PW2 + (64 * c + 32 * kp + m16) * 2;
-        dw.w2l[1] = OFF_W2 + (5 + 4 * (g4 & 1)) * PW2 + (64 * c + 32 * kp + m16) * 2;
+        dw.tb = tb + eb * ES_BYTES + 64 * kp;
+        dw.set_lane(m16, g4);   // rebuilt per slice from the lane index: registers that need not live through the expand stage
+        dw.w2l = OFF_W2 + (g4 & 1) * dw_wplane(CEXP) + (64 * c + 32 * kp + m16) * 4;
         dw.pb = OFF_B2 + 256 * c + 128 * kp + 16 * g4;
         dw.w3l = (wb ? OFF_WB1 : OFF_WB0) + W1_BYTES + (16 * (g4 & 1) + m16) * PW3 + 16 * (g4 >> 1) + 32 * kp;
         dw.preamble();
@@ -450,7 +442,7 @@ constexpr int block_lds_bytes() {
     constexpr int wb = 64 * (CIN * 2 + 16) + COUT * 160;
     constexpr int epi = KSPLIT * TR * (H / S) * (COUT * 4 + 16);
     constexpr int off_par = (cmax(es + wb, epi) + 15) / 16 * 16;
-    return off_par + 4 * CEXP * 4 + 13 * (CEXP * 2 + 32) + wb;
+    return off_par + 4 * CEXP * 4 + dw_wimage_bytes(CEXP) + wb;
 }
 
 // workgroups of `kernel` that fit on the current device at once (occupancy x compute units)

@@ -226,14 +226,12 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     const int wt = SSPLIT ? we : wave;
     const bool dw_active = SSPLIT ? (we < MTO && en < 2) : (wt < MTO);
     constexpr int ST1 = POW == 32 ? 16 * SLOT : (16 / POW) * PITCH * SLOT;
-    static_assert(ST1 + 2 * PITCH * SLOT + 96 < 65536, "tap offsets must fit the instruction's offset field");
-    int tb[2];            // LDS byte address of unit (g >> 1) of tap 0 / 1 and of tap 5 / 2 (DwStage::tb)
+    static_assert(ST1 + 2 * PITCH * SLOT + 112 < 65536, "tap offsets must fit the instruction's offset field");
+    int tb;               // LDS byte address of this lane's tap (0, min(g, 2)) (DwStage::tb)
     {
         const int oy = wt * RPT + m16 / POW, ox = m16 % POW;
-        const int h1 = g4 & 1;
         const int sub = SSPLIT ? en * ST1 : 0;                                 // (SSPLIT) this wave's subtile
-        tb[0] = (oy * PITCH + ox + h1) * SLOT + 16 * (g4 >> 1) + sub;          // tap 0 = (0,0) / tap 1 = (0,1)
-        tb[1] = ((oy + 1 - h1) * PITCH + ox + 2) * SLOT + 16 * (g4 >> 1) + sub;  // tap 5 = (1,2) / tap 2 = (0,2)
+        tb = (oy * PITCH + ox + (g4 < 2 ? g4 : 2)) * SLOT + sub;
     }
     f32x4 pacc[NSUB][NT16];  // tile n of subtile st, register i <-> output channel 16 n + 4 g + i
 
@@ -257,13 +255,9 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
         if (!dw_active) return;                            // wave-uniform
         const int base = ES_BYTES + buf * PK::BYTES;
         DwStage<T, 64, NT16, PK::PW3, ST1, PITCH * SLOT, 4, NSUB> dw;
-        dw.tb[0] = tb[0];
-        dw.tb[1] = tb[1];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            dw.msk[i] = ((m16 >> 3) == (g4 >> 1) && ((m16 & 7) >> 1) == i) ? ((m16 & 1) ? 0xFFFF0000u : 0x0000FFFFu) : 0u;
-        dw.w2l[0] = base + PK::OFF_W2 + (g4 & 1) * PK::PW2 + m16 * 2;
-        dw.w2l[1] = base + PK::OFF_W2 + (5 + 4 * (g4 & 1)) * PK::PW2 + m16 * 2;
+        dw.tb = tb;
+        dw.set_lane(m16, g4);
+        dw.w2l = base + PK::OFF_W2 + (g4 & 1) * dw_wplane(64) + m16 * 4;
         dw.pb = base + PK::OFF_B2 + 16 * g4;
         dw.w3l = base + PK::OFF_W3 + (16 * (g4 & 1) + m16) * PK::PW3 + 16 * (g4 >> 1);
         dw.preamble();
@@ -474,9 +468,11 @@ static void pack_rblock_c(int dt, int cexp, const float* w1, const float* b1, co
             reinterpret_cast<float*>(pk + PK::OFF_S1)[el] = s1[e] - 1.0f;
             reinterpret_cast<float*>(pk + PK::OFF_B2)[pos] = b2[e];
             reinterpret_cast<float*>(pk + PK::OFF_S2)[pos] = s2[e] - 1.0f;
-            for (int r = 0; r < 10; ++r) {                 // rows 0..8 the taps, row 9 tap 2 again, rows 10..12 stay zero
-                const int tap = r == 9 ? 2 : r;
-                reinterpret_cast<uint16_t*>(pk + PK::OFF_W2 + r * PK::PW2)[pos] = rb_to16(dt, w2[(size_t)e * 9 + tap]);
+            for (int r = 0; r < 3; ++r) {                  // window row r: plane 0 = taps (r,0) | (r,1) << 16, plane 1 = tap (r,2)
+                unsigned char* row = pk + PK::OFF_W2 + r * dw_wrow(64);
+                reinterpret_cast<uint32_t*>(row)[pos] =
+                    (uint32_t)rb_to16(dt, w2[(size_t)e * 9 + 3 * r]) | ((uint32_t)rb_to16(dt, w2[(size_t)e * 9 + 3 * r + 1]) << 16);
+                reinterpret_cast<uint32_t*>(row + dw_wplane(64))[pos] = (uint32_t)rb_to16(dt, w2[(size_t)e * 9 + 3 * r + 2]);
             }
             const int P = (pos >> 5) & 1, hi = (pos >> 4) & 1, g = (pos >> 2) & 3, i = pos & 3;
             for (int co = 0; co < C; ++co) {

@@ -8,7 +8,7 @@ sd = {k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(1, 512).items
 nets = []
 for _ in range(4):
     n = MobileFaceNet(512); n.load_state_dict(sd); nets.append(n.to(dev).eval())
-B = 1024
+B = int(os.environ.get("FRA_B", "1024"))
 x = torch.randn(B, 3, 112, 112, device=dev)
 def run(parts, steps=150):
     streams = [torch.cuda.Stream() for _ in range(parts)]
