@@ -150,7 +150,11 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     // accumulates its own partial project sums; the epilogue adds the two.  MTOW: tiles rounded up to a power of two.
     constexpr int MTOW = MTO > 4 ? 8 : (MTO > 2 ? 4 : (MTO > 1 ? 2 : 1));
     static_assert(KSPLIT == 1 || KSPLIT == 2, "chunk pairs of a slice");
-    static_assert(KSPLIT * MTOW <= NW || (KSPLIT == 1 && MTO <= NW), "one (output tile, chunk pair) per wave");
+    // (KSPLIT == 1) a band with more output tiles than waves gives wave w the tiles w, w + NW, ...: one after the other
+    // in the depthwise + project stage, each with its own project accumulators
+    constexpr int MTOT = KSPLIT == 1 ? (MTO + NW - 1) / NW : 1;
+    static_assert(KSPLIT == 1 || KSPLIT * MTOW <= NW, "one (output tile, chunk pair) per wave");
+    constexpr int TSTEP = NW * RPT;                        // output rows between two tiles of a wave
     static_assert(!RESID || (S == 1 && CIN == COUT), "shortcut needs matching shapes");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(LDS_BYTES == block_lds_bytes<CIN, CEXP, COUT, H, S, TR, MODE, KSPLIT>(), "the launcher's LDS size is this map's");
@@ -235,7 +239,7 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     // ---- output pixels of this lane on the depthwise / project side: pixel m of each 16-pixel subtile ----------
     const int m16 = lane & 15, g4 = lane >> 4;
     const int wt = KSPLIT == 1 ? wave : (wave & (MTOW - 1)), kp = KSPLIT == 1 ? 0 : wave / MTOW;   // wave-uniform
-    const bool dw_active = wt < MTO && kp < KSPLIT;
+    const bool dw_active = wt < MTO && kp < KSPLIT;        // (tile 0; a wave without tile 0 has no later tile either)
     // Subtile 1 holds the pixels 16 lanes further on in the tile: 16 columns further (one tile row of 32), the next
     // row (16) or two rows further (8), always a fixed number of bytes after subtile 0's.  Lanes without an
     // output pixel still read -- their own (unused) column and row, so that the 16 lanes of a read group keep
@@ -245,19 +249,22 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     constexpr int ST1 = POW == 32 ? 16 * S * SLOT : (16 / POW) * S * PITCH * SLOT;
     static_assert(ST1 + 96 < 65536, "subtile offset must fit the instruction's offset field");
     static_assert(ST1 + 2 * PITCH * SLOT + 112 < 65536, "tap offsets must fit the instruction's offset field");
-    int tb;               // LDS byte address of this lane's tap (0, min(g, 2)) (see DwStage::tb)
-    bool out_ok[2];
-    int po0;              // this lane's pixel of subtile 0 inside the band; subtile 1 is PO1 further
+    int tb;               // LDS byte address of this lane's tap (0, min(g, 2)) in tile 0 (see DwStage::tb); tile t: + t TSTEP S rows
+    bool out_ok[MTOT][2];
+    int po0;              // this lane's pixel of subtile 0 of tile 0 inside the band; subtile 1 is PO1 further, tile t is t TSTEP rows further
     constexpr int PO1 = POW == 32 ? 16 : (16 / POW) * Wo;
     {
         const int oy = wt * RPT + m16 / POW, ox = m16 % POW;
         po0 = oy * Wo + ox;
-        out_ok[0] = (ox < Wo) && (oy < TR);
-        out_ok[1] = POW == 32 ? (ox + 16 < Wo) && (oy < TR) : (ox < Wo) && (oy + 16 / POW < TR);
+#pragma unroll
+        for (int t = 0; t < MTOT; ++t) {
+            out_ok[t][0] = (ox < Wo) && (oy + t * TSTEP < TR);
+            out_ok[t][1] = POW == 32 ? (ox + 16 < Wo) && (oy + t * TSTEP < TR) : (ox < Wo) && (oy + t * TSTEP + 16 / POW < TR);
+        }
         tb = ((oy * S) * PITCH + ox * S + (g4 < 2 ? g4 : 2)) * SLOT;
     }
     // project accumulators: tile n of subtile st, register i <-> output channel 16 n + 4 g + i; the bias joins in the epilogue
-    f32x4 pacc[2][NT16];
+    f32x4 pacc[MTOT][2][NT16];
 
     // ================= expand of slice c: E[64 ch][pixels] = PReLU(W1 . X + b1) -> LDS image =================
     typedef ExpStage<T, KS1, CEXP, PW1> Ex;
@@ -309,14 +316,18 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
     auto dwproject = [&](int c, int wb, int eb) {
         if (!dw_active) return;                            // wave-uniform
         DwStage<T, CEXP, NT16, PW3, ST1, PITCH * SLOT, 4 / KSPLIT> dw;
-        // a wave that takes chunk pair kp of the slice starts 2 kp chunks further in every per-chunk array
-        dw.tb = tb + eb * ES_BYTES + 64 * kp;
         dw.set_lane(m16, g4);   // rebuilt per slice from the lane index: registers that need not live through the expand stage
+        // a wave that takes chunk pair kp of the slice starts 2 kp chunks further in every per-chunk array
         dw.w2l = OFF_W2 + (g4 & 1) * dw_wplane(CEXP) + (64 * c + 32 * kp + m16) * 4;
         dw.pb = OFF_B2 + 256 * c + 128 * kp + 16 * g4;
         dw.w3l = (wb ? OFF_WB1 : OFF_WB0) + W1_BYTES + (16 * (g4 & 1) + m16) * PW3 + 16 * (g4 >> 1) + 32 * kp;
-        dw.preamble();
-        dw.run(pacc);
+#pragma unroll
+        for (int t = 0; t < MTOT; ++t) {
+            if (t > 0 && wt + NW * t >= MTO) break;        // wave-uniform
+            dw.tb = tb + eb * ES_BYTES + 64 * kp + t * (TSTEP * S * PITCH * SLOT);
+            dw.preamble();
+            dw.run(pacc[t]);
+        }
     };
 
     // A workgroup keeps its band and walks over images blockIdx.y, blockIdx.y + gridDim.y, ...: the per-channel
@@ -345,9 +356,11 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         if (img == (int)blockIdx.y) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+        for (int t = 0; t < MTOT; ++t)
 #pragma unroll
-            for (int n = 0; n < NT16; ++n) pacc[st][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int n = 0; n < NT16; ++n) pacc[t][st][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         // per slice: request the next slice's weights (or the next image's first slice) into the other buffer |
         // expand | barrier | depthwise + project | wait for the requested pieces | barrier
 #pragma unroll 1
@@ -392,12 +405,14 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         fetch_shortcut(std::integral_constant<int, 0>{});
         if (dw_active) {
     #pragma unroll
-            for (int st = 0; st < 2; ++st)
-                if (out_ok[st]) {
-                    char* dst = lds + kp * EPI1 + (po0 + st * PO1) * P32 + 16 * g4;
+            for (int t = 0; t < MTOT; ++t)
     #pragma unroll
-                    for (int n = 0; n < NT16; ++n) *reinterpret_cast<f32x4*>(dst + 64 * n) = pacc[st][n];
-                }
+                for (int st = 0; st < 2; ++st)
+                    if (out_ok[t][st]) {
+                        char* dst = lds + kp * EPI1 + (po0 + t * (TSTEP * Wo) + st * PO1) * P32 + 16 * g4;
+    #pragma unroll
+                        for (int n = 0; n < NT16; ++n) *reinterpret_cast<f32x4*>(dst + 64 * n) = pacc[t][st][n];
+                    }
         }
         __syncthreads();
         {
@@ -498,7 +513,7 @@ static int compute_units() {
     return cus;
 }
 
-// Two band heights per shape.  The tall one has the least halo work and is what a full batch runs; with only a
+// Two band heights per shape (three for conv_3).  The tall one has the least halo work and is what a full batch runs; with only a
 // few images it would leave most of the chip idle (conv_4 as whole-image bands: ONE workgroup per image), so
 // a batch whose SHORT bands still fit the chip in one go (one workgroup per compute unit) runs those: more
 // redundant expand rows, but 7 to 14 workgroups per image side by side.
@@ -511,9 +526,15 @@ static int launch_block_t(const BlockParams& p, const void* x, void* out, int B,
         case 64 * 1000000 + 128 * 1000 + 56 * 10 + 2:   // conv_23
             return few ? launch_block_cfg<T, 64, 128, 64, 56, 2, 2, false, 8, 2, 1, true, 2>(p, x, out, B, s)
                        : launch_block_cfg<T, 64, 128, 64, 56, 2, 4, false, 8, 2, 1, true, 2>(p, x, out, B, s);
-        case 64 * 1000000 + 128 * 1000 + 28 * 10 + 1:   // conv_3.*
-            return few ? launch_block_cfg<T, 64, 128, 64, 28, 1, 2, true, 8, 2, 1, true, 1>(p, x, out, B, s)
-                       : launch_block_cfg<T, 64, 128, 64, 28, 1, 7, true, 8, 2, 1, true, 1>(p, x, out, B, s);
+        case 64 * 1000000 + 128 * 1000 + 28 * 10 + 1: { // conv_3.*
+            if (few) return launch_block_cfg<T, 64, 128, 64, 28, 1, 2, true, 8, 2, 1, true, 1>(p, x, out, B, s);
+            // 14-row bands (two output tiles per wave, half the halo rows and half the per-band phases of 7-row
+            // bands) cost 1.9 times a 7-row band: take whichever needs less time for its rounds over the chip
+            const int cus = compute_units();
+            const int64_t cost7 = ((int64_t)4 * B + cus - 1) / cus * 10, cost14 = ((int64_t)2 * B + cus - 1) / cus * 19;
+            return cost14 < cost7 ? launch_block_cfg<T, 64, 128, 64, 28, 1, 14, true, 8, 2, 1, true, 1>(p, x, out, B, s)
+                                  : launch_block_cfg<T, 64, 128, 64, 28, 1, 7, true, 8, 2, 1, true, 1>(p, x, out, B, s);
+        }
         case 64 * 1000000 + 256 * 1000 + 28 * 10 + 2:   // conv_34
             return few ? launch_block_cfg<T, 64, 256, 128, 28, 2, 2, false, 8, 2, 1, true, 2>(p, x, out, B, s)
                        : launch_block_cfg<T, 64, 256, 128, 28, 2, 7, false, 8, 2, 1, true, 2>(p, x, out, B, s);

@@ -125,10 +125,12 @@ def test_chained_and_per_block_launches_agree_bit_for_bit(hip_model, device):
 
 def test_band_configurations_agree_bit_for_bit(hip_model, device):
     """The block kernels run short bands while those fit the chip in one go (up to 18 or 36 images, depending on
-    the layer) and tall bands beyond: batches on every side of both limits give the same rows."""
-    x = torch.from_numpy(synthetic.make_crops(40, 13)).to(device)
-    want = hip_model(x).cpu()                      # 40: tall bands everywhere
-    for B in (1, 18, 19, 36, 37):
+    the layer) and tall bands beyond; conv_3 has two tall heights (7 and 14 rows, whichever needs less time for its
+    rounds over the chip: 14 rows at 100 images, 7 rows at 40 and 64).  Batches on every side of the limits give
+    the same rows."""
+    x = torch.from_numpy(synthetic.make_crops(100, 13)).to(device)
+    want = hip_model(x).cpu()                      # 100: tall bands everywhere, 14-row bands in conv_3
+    for B in (1, 18, 19, 36, 37, 40, 64):
         assert torch.equal(hip_model(x[:B].contiguous()).cpu(), want[:B]), B
 
 
