@@ -113,9 +113,10 @@ typedef __attribute__((address_space(3))) void* LPTR;        // its (wave-unifor
 template <int KS> struct TopList {
     float s[KS];
     int id[KS];
-    __device__ __forceinline__ void init() {
+    // empty slots carry id -1 and the score `floor`: only rows that score above it are ever taken in
+    __device__ __forceinline__ void init(float floor) {
 #pragma unroll
-        for (int j = 0; j < KS; ++j) { s[j] = -INFINITY; id[j] = -1; }
+        for (int j = 0; j < KS; ++j) { s[j] = floor; id[j] = -1; }
     }
     // rows reach a lane in increasing order, so on equal scores the resident (lower) row stays ahead
     __device__ __forceinline__ void insert(float v, int row) {
@@ -255,6 +256,7 @@ template <typename T, int KS>
 __global__ __launch_bounds__(512) void search_kernel(const T* __restrict__ G, const float* __restrict__ negh,
                                                      const T* __restrict__ Qh, const float* __restrict__ qn,
                                                      float* __restrict__ pdist, int* __restrict__ pidx,
+                                                     const float* __restrict__ qfloor, int tile0,
                                                      int tiles_total, int tiles_per_split, int QT, int S, int Qpad,
                                                      int index_base) {
     typedef typename vec8<T>::type V8;
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(512) void search_kernel(const T* __restrict__ G, co
         if ((S & 7) == 0) { const int j = b >> 3; split = (b & 7) + 8 * (j / QT); qt = j % QT; }
         else { qt = b % QT; split = b / QT; }
     }
-    const int t_begin = split * tiles_per_split;
+    const int t_begin = tile0 + split * tiles_per_split;
     int t_end = t_begin + tiles_per_split;
     if (t_end > tiles_total) t_end = tiles_total;
 
@@ -289,8 +291,10 @@ __global__ __launch_bounds__(512) void search_kernel(const T* __restrict__ G, co
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             c.qf[s][u] = *reinterpret_cast<const V8*>(Qh + (size_t)(qrow0 + 16 * u) * D + s * 32 + kg * 8);
-    c.top[0].init();
-    c.top[1].init();
+    // qfloor: per query a score that its k-th best row is known to beat (from a pass over other rows); the lists
+    // then skip everything below it from their first row on instead of filling up with whatever comes first
+    c.top[0].init(qfloor ? qfloor[qrow0] : -INFINITY);
+    c.top[1].init(qfloor ? qfloor[qrow0 + 16] : -INFINITY);
 
     // A fragment of step (rt, ks): row 16 rt + col, chunk 4 ks + kg  ->  lane part lo[ks & 3] plus the
     // compile-time part 256 (ks >> 2) + 16384 rt
@@ -401,6 +405,10 @@ __device__ __forceinline__ bool pair_less(float d1, int i1, float d2, int i2) {
     return d1 < d2 || (d1 == d2 && i1 < i2);
 }
 
+// CACHE > 0: the candidates number at most 256 CACHE and a thread keeps its share in registers over the rounds
+// (partial lists of a search, shard lists of a merge); CACHE == 0: every round reads them again (a dense distance row).
+static const int SELECT_CACHE = 8;
+template <int CACHE>
 __global__ __launch_bounds__(256) void select_topk_kernel(const float* __restrict__ dist, const int* __restrict__ idx,
                                                           int lists, long strideL, long strideQ, int len,
                                                           int index_base, int k, float* __restrict__ dist_out,
@@ -412,17 +420,43 @@ __global__ __launch_bounds__(256) void select_topk_kernel(const float* __restric
     const long total = (long)lists * len;
     float last_d = -INFINITY;
     int last_i = -1;
+    float cd[CACHE > 0 ? CACHE : 1];
+    int ci[CACHE > 0 ? CACHE : 1];
+    if constexpr (CACHE > 0) {
+#pragma unroll
+        for (int u = 0; u < CACHE; ++u) {
+            const long c = tid + 256L * u;
+            cd[u] = INFINITY;
+            ci[u] = -1;
+            if (c < total) {
+                const long l = c / len, j = c - l * len;
+                const long a = l * strideL + (long)q * strideQ + j;
+                cd[u] = dist[a];
+                ci[u] = idx ? idx[a] : (int)j + index_base;
+            }
+        }
+    }
     for (int round = 0; round < k; ++round) {
         float bd = INFINITY;
         int bi = 0x7fffffff;
-        for (long c = tid; c < total; c += 256) {
-            const long l = c / len, j = c - l * len;
-            const long a = l * strideL + (long)q * strideQ + j;
-            const float d = dist[a];
-            const int i = idx ? idx[a] : (int)j + index_base;
-            if (i < 0) continue;
-            if (round > 0 && !pair_less(last_d, last_i, d, i)) continue;
-            if (pair_less(d, i, bd, bi)) { bd = d; bi = i; }
+        if constexpr (CACHE > 0) {
+#pragma unroll
+            for (int u = 0; u < CACHE; ++u) {
+                const float d = cd[u];
+                const int i = ci[u];
+                const bool open = i >= 0 && (round == 0 || pair_less(last_d, last_i, d, i));
+                if (open && pair_less(d, i, bd, bi)) { bd = d; bi = i; }
+            }
+        } else {
+            for (long c = tid; c < total; c += 256) {
+                const long l = c / len, j = c - l * len;
+                const long a = l * strideL + (long)q * strideQ + j;
+                const float d = dist[a];
+                const int i = idx ? idx[a] : (int)j + index_base;
+                if (i < 0) continue;
+                if (round > 0 && !pair_less(last_d, last_i, d, i)) continue;
+                if (pair_less(d, i, bd, bi)) { bd = d; bi = i; }
+            }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -456,6 +490,40 @@ __global__ __launch_bounds__(256) void select_topk_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// score floor of each query from the partial lists of a pass over PART of the gallery: the k-th smallest
+// distance d_k among them bounds the k-th smallest over the whole gallery from above, so every row of the final
+// answer scores at least (|q|^2 - d_k) / 2.  The floor is that score minus a margin for the two roundings
+// between a score and its distance (rows that TIE with the k-th best must still pass the lists' strict
+// comparison).  Fewer than k candidates: no floor.  One thread per query.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void score_floor_kernel(const float* __restrict__ pdist, const int* __restrict__ pidx,
+                                                          const float* __restrict__ qn, int lists, int Qpad, int KS, int k,
+                                                          float* __restrict__ qfloor) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Qpad) return;
+    float best[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) best[j] = INFINITY;       // ascending; best[k - 1] is the k-th smallest so far
+    for (int l = 0; l < lists; ++l)
+        for (int j = 0; j < KS; ++j) {
+            const size_t a = ((size_t)l * Qpad + q) * KS + j;
+            if (pidx[a] < 0) continue;
+            float d = pdist[a];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {                  // insertion by compare-exchange, all in registers
+                const float lo = fminf(best[i], d), hi = fmaxf(best[i], d);
+                best[i] = lo;
+                d = hi;
+            }
+        }
+    float dk = INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (i == k - 1) dk = best[i];
+    const float q2 = qn[q];
+    qfloor[q] = dk < INFINITY ? 0.5f * (q2 - dk) - 4e-7f * (fabsf(q2) + dk) - 1e-30f : -INFINITY;
+}
+
 __global__ __launch_bounds__(256) void threshold_score_kernel(const float* __restrict__ minimum,
                                                               long long* __restrict__ idx,
                                                               float* __restrict__ score, int Q, float limit) {
@@ -474,6 +542,16 @@ __global__ __launch_bounds__(256) void threshold_score_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+static void launch_select(hipStream_t s, int Q, const float* dist, const int* idx, int lists, long strideL, long strideQ, int len,
+                          int index_base, int k, float* dist_out, int* idx_out) {
+    if ((long)lists * len <= 256L * SELECT_CACHE)
+        hipLaunchKernelGGL(select_topk_kernel<SELECT_CACHE>, dim3(Q), dim3(256), 0, s, dist, idx, lists, strideL, strideQ, len,
+                           index_base, k, dist_out, idx_out);
+    else
+        hipLaunchKernelGGL(select_topk_kernel<0>, dim3(Q), dim3(256), 0, s, dist, idx, lists, strideL, strideQ, len, index_base, k,
+                           dist_out, idx_out);
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int ensure_scratch(fb_handle* h, size_t bytes) {
@@ -572,29 +650,32 @@ static int take_scratch(fb_handle* h, size_t need, char* fixed, size_t cap, char
 
 template <typename T, int KSV>
 static int launch_search(const dim3 grid, size_t lds, hipStream_t s, const T* G, const float* negh, const T* qh,
-                         const float* qn, float* pd, int* pi, int tiles, int tps, int QT, int S, int Qpad, int index_base) {
+                         const float* qn, float* pd, int* pi, const float* qfloor, int tile0, int tiles, int tps, int QT, int S,
+                         int Qpad, int index_base) {
     static std::atomic<uint64_t> lds_set;      // per instantiation: devices whose LDS limit is raised
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&search_kernel<T, KSV>), (int)lds, lds_set)) return rc;
-    hipLaunchKernelGGL((search_kernel<T, KSV>), grid, dim3(512), lds, s, G, negh, qh, qn, pd, pi, tiles, tps, QT, S, Qpad,
-                       index_base);
+    hipLaunchKernelGGL((search_kernel<T, KSV>), grid, dim3(512), lds, s, G, negh, qh, qn, pd, pi, qfloor, tile0, tiles, tps, QT,
+                       S, Qpad, index_base);
     FRA_HIP(hipGetLastError());
     return FRA_OK;
 }
 
-template <typename T>
-static int search_packed(fb_handle* h, const float* queries, int Q, int k, float* dist_out, int32_t* idx_out,
-                         hipStream_t s, char* fixed, size_t cap) {
-    const int D = h->D;
-    const int QT = (Q + BQ - 1) / BQ, Qpad = QT * BQ;
-    const int tiles = (int)(h->Npad / BG);
-    const int KS = k == 1 ? 1 : (k <= 5 ? 5 : 8);
-    // Gallery splits.  A block occupies a compute unit alone (LDS) and all blocks of a search do equal work, so the
-    // grid should be a whole number of rounds over the chip: among the multiples of 8 (the XCD-aware block mapping)
-    // up to 64 (=> 256 partial lists per query) take the split count that wastes the least of its last round, the
-    // smaller one on ties; a gallery of fewer than 8 tiles gets one split per tile.
+template <typename T, int KSV>
+static int launch_search_ks(int KS, const dim3 grid, size_t lds, hipStream_t s, const T* G, const float* negh, const T* qh,
+                            const float* qn, float* pd, int* pi, const float* qfloor, int tile0, int tiles, int tps, int QT,
+                            int S, int Qpad, int index_base) {
+    if (KS == KSV) return launch_search<T, KSV>(grid, lds, s, G, negh, qh, qn, pd, pi, qfloor, tile0, tiles, tps, QT, S, Qpad, index_base);
+    if constexpr (KSV == 1) return launch_search_ks<T, 5>(KS, grid, lds, s, G, negh, qh, qn, pd, pi, qfloor, tile0, tiles, tps, QT, S, Qpad, index_base);
+    else return launch_search<T, 8>(grid, lds, s, G, negh, qh, qn, pd, pi, qfloor, tile0, tiles, tps, QT, S, Qpad, index_base);
+}
+
+// Split count for `tiles` gallery tiles and QT query tiles.  A block occupies a compute unit alone (LDS) and all
+// blocks of a search do equal work, so the grid should be a whole number of rounds over the chip: among the
+// multiples of 8 (the XCD-aware block mapping) up to 64 (=> 256 partial lists per query) take the split count that
+// wastes the least of its last round, the smaller one on ties; fewer than 8 tiles get one split per tile.
+static void choose_splits(int tiles, int QT, int cus, int* S_out, int* tps_out) {
     int S = tiles < 8 ? tiles : 8;
     if (tiles >= 8) {
-        const int cus = search_compute_units();
         double best = -1.0;
         for (int cand = 8; cand <= 64 && cand <= tiles; cand += 8) {
             const long blocks = (long)QT * cand;
@@ -604,34 +685,79 @@ static int search_packed(fb_handle* h, const float* queries, int Q, int k, float
         }
     }
     const int tps = (tiles + S - 1) / S;
-    S = (tiles + tps - 1) / tps;  // drop empty splits
-    const int P = 4 * S;   // four partial lists (lane groups) per split
+    *S_out = (tiles + tps - 1) / tps;  // drop empty splits
+    *tps_out = tps;
+}
+
+static const int SEARCH_MAX_LISTS = 4 * (64 + 8);   // partial lists per query: main pass + floor pass
+
+#ifndef SEARCH_T1_COEF
+#define SEARCH_T1_COEF 0.5
+#endif
+#ifndef SEARCH_FLOOR_PASS
+#define SEARCH_FLOOR_PASS 1
+#endif
+template <typename T>
+static int search_packed(fb_handle* h, const float* queries, int Q, int k, float* dist_out, int32_t* idx_out,
+                         hipStream_t s, char* fixed, size_t cap) {
+    const int D = h->D;
+    const int QT = (Q + BQ - 1) / BQ, Qpad = QT * BQ;
+    const int tiles = (int)(h->Npad / BG);
+    const int KS = k == 1 ? 1 : (k <= 5 ? 5 : 8);
+    const int cus = search_compute_units();
+    // A per-lane list starts empty and takes in most of its first few hundred rows, and while ANY of a wave's 512
+    // candidates passes its list the wave runs the divergent insertion path; with lists of a few thousand rows
+    // (a million-row gallery over 32 splits) that is most chains.  So such a search runs in two passes: the first
+    // T1 tiles in one round over the chip, the k-th best distance they give per query as a score floor, then the
+    // rest with lists that start at that floor (the fraction of rows that pass it is k / (48 T1) from the first
+    // tile on).  T1 balances the first pass's time against the insertions it saves: ~ sqrt(tiles QT / 2), and flat around it.
+    int T1 = 0, S1 = 0, tps1 = 0;
+    if (SEARCH_FLOOR_PASS) {
+        int S0, tps0;
+        choose_splits(tiles, QT, cus, &S0, &tps0);
+        const double t1 = sqrt(SEARCH_T1_COEF * (double)tiles * (double)QT);
+        if (t1 >= 48.0 && t1 <= tiles / 4 && (long)tps0 * (BG / 4) < 150000) {
+            S1 = cus / QT < 1 ? 1 : (cus / QT > 8 ? 8 : cus / QT);
+            tps1 = ((int)t1 + S1 - 1) / S1;
+            T1 = tps1 * S1;
+        }
+    }
+    int S, tps;
+    choose_splits(tiles - T1, QT, cus, &S, &tps);
+    const int P1 = 4 * S1, P = 4 * S;   // four partial lists (lane groups) per split
 
     size_t off_qh = 0, off_qn = align_up(off_qh + (size_t)Qpad * D * 2, 256),
-           off_pd = align_up(off_qn + (size_t)Qpad * 4, 256),
-           off_pi = align_up(off_pd + (size_t)P * Qpad * KS * 4, 256),
-           total = align_up(off_pi + (size_t)P * Qpad * KS * 4, 256);
+           off_fl = align_up(off_qn + (size_t)Qpad * 4, 256),
+           off_pd = align_up(off_fl + (size_t)Qpad * 4, 256),
+           off_pi = align_up(off_pd + (size_t)(P1 + P) * Qpad * KS * 4, 256),
+           total = align_up(off_pi + (size_t)(P1 + P) * Qpad * KS * 4, 256);
     char* sc = nullptr;
     int rc = take_scratch(h, total, fixed, cap, &sc);
     if (rc) return rc;
-    // every byte of these four arrays that a later kernel reads is written by an earlier kernel of this
-    // call (all Qpad query rows, all P lists of every query), so stale scratch contents are harmless
+    // every byte of these arrays that a later kernel reads is written by an earlier kernel of this
+    // call (all Qpad query rows, all lists of every query), so stale scratch contents are harmless
     T* qh = reinterpret_cast<T*>(sc + off_qh);
     float* qn = reinterpret_cast<float*>(sc + off_qn);
+    float* fl = reinterpret_cast<float*>(sc + off_fl);
     float* pd = reinterpret_cast<float*>(sc + off_pd);
     int* pi = reinterpret_cast<int*>(sc + off_pi);
 
     hipLaunchKernelGGL(prep_queries_kernel<T>, dim3((Qpad + 3) / 4), dim3(256), 0, s, queries, qh, qn, Q, Qpad, D);
     FRA_HIP(hipGetLastError());
     const size_t lds = 3 * (size_t)SEARCH_BUF_BYTES;
-    const dim3 grid((unsigned)(QT * S));
     const T* G = static_cast<const T*>(h->rows);
-    if (KS == 1) rc = launch_search<T, 1>(grid, lds, s, G, h->negh, qh, qn, pd, pi, tiles, tps, QT, S, Qpad, (int)h->index_base);
-    else if (KS == 5) rc = launch_search<T, 5>(grid, lds, s, G, h->negh, qh, qn, pd, pi, tiles, tps, QT, S, Qpad, (int)h->index_base);
-    else rc = launch_search<T, 8>(grid, lds, s, G, h->negh, qh, qn, pd, pi, tiles, tps, QT, S, Qpad, (int)h->index_base);
+    if (T1 > 0) {
+        rc = launch_search_ks<T, 1>(KS, dim3((unsigned)(QT * S1)), lds, s, G, h->negh, qh, qn, pd, pi, nullptr, 0, T1, tps1, QT, S1,
+                                    Qpad, (int)h->index_base);
+        if (rc) return rc;
+        hipLaunchKernelGGL(score_floor_kernel, dim3((Qpad + 255) / 256), dim3(256), 0, s, pd, pi, qn, P1, Qpad, KS, k, fl);
+        FRA_HIP(hipGetLastError());
+    }
+    const size_t o1 = (size_t)P1 * Qpad * KS;
+    rc = launch_search_ks<T, 1>(KS, dim3((unsigned)(QT * S)), lds, s, G, h->negh, qh, qn, pd + o1, pi + o1, T1 > 0 ? fl : nullptr, T1,
+                                tiles, tps, QT, S, Qpad, (int)h->index_base);
     if (rc) return rc;
-    hipLaunchKernelGGL(select_topk_kernel, dim3(Q), dim3(256), 0, s, pd, pi, P, (long)Qpad * KS, (long)KS, KS, 0, k,
-                       dist_out, idx_out);
+    launch_select(s, Q, pd, pi, P1 + P, (long)Qpad * KS, (long)KS, KS, 0, k, dist_out, idx_out);
     FRA_HIP(hipGetLastError());
     return FRA_OK;
 }
@@ -664,8 +790,8 @@ static int search_f32(fb_handle* h, const float* queries, int Q, int k, float* d
         hipLaunchKernelGGL(l2dist_f32_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, queries + (size_t)q0 * h->D,
                            static_cast<const float*>(h->rows), dist, m, (long)h->N, h->D);
         FRA_HIP(hipGetLastError());
-        hipLaunchKernelGGL(select_topk_kernel, dim3(m), dim3(256), 0, s, dist, (const int*)nullptr, 1, 0L, (long)h->N,
-                           (int)h->N, (int)h->index_base, k, dist_out + (size_t)q0 * k, idx_out + (size_t)q0 * k);
+        launch_select(s, m, dist, (const int*)nullptr, 1, 0L, (long)h->N, (int)h->N, (int)h->index_base, k,
+                      dist_out + (size_t)q0 * k, idx_out + (size_t)q0 * k);
         FRA_HIP(hipGetLastError());
     }
     return FRA_OK;
@@ -818,8 +944,8 @@ int fb_reserve(fb_handle* h, int max_queries) {
         return ensure_scratch(h, align_up(need, 256));
     }
     const int QT = (max_queries + BQ - 1) / BQ, Qpad = QT * BQ;
-    const size_t P = 256, KS = 8;   // upper bounds of the partial-list layout in search_packed
-    return ensure_scratch(h, align_up((size_t)Qpad * h->D * 2, 256) + align_up((size_t)Qpad * 4, 256) +
+    const size_t P = SEARCH_MAX_LISTS, KS = 8;   // upper bounds of the partial-list layout in search_packed
+    return ensure_scratch(h, align_up((size_t)Qpad * h->D * 2, 256) + 2 * align_up((size_t)Qpad * 4, 256) +
                                  2 * align_up(P * Qpad * KS * 4, 256));
 }
 
@@ -847,8 +973,7 @@ int fb_merge_topk(const float* dist_in, const int32_t* idx_in, int R, int Q, int
                   int32_t* idx_out, fra_stream stream) {
     FRA_REQUIRE(dist_in && idx_in && dist_out && idx_out, FRA_ERR_ARG, "fb_merge: null pointer");
     FRA_REQUIRE(R > 0 && Q > 0 && k >= 1 && k <= 8, FRA_ERR_ARG, "fb_merge: bad shape R=%d Q=%d k=%d", R, Q, k);
-    hipLaunchKernelGGL(select_topk_kernel, dim3(Q), dim3(256), 0, (hipStream_t)stream, dist_in, idx_in, R,
-                       (long)Q * k, (long)k, k, 0, k, dist_out, idx_out);
+    launch_select((hipStream_t)stream, Q, dist_in, idx_in, R, (long)Q * k, (long)k, k, 0, k, dist_out, idx_out);
     FRA_HIP(hipGetLastError());
     return FRA_OK;
 }

@@ -114,6 +114,41 @@ def test_topk_f16_one_million_rows_vs_bruteforce(device):
     gal.close()
 
 
+def test_two_pass_search_keeps_ties_across_the_passes(device):
+    """Galleries of some hundred thousand rows are searched in two passes: the first few thousand rows give every
+    query a score floor, the rest is searched with lists that start at that floor.  A row of the first part that is
+    DUPLICATED in the second part ties with its copy at distance 0; both must come back, lower index first, and
+    the rest of the list must be the brute force's -- for queries whose k-th best sits in the first part
+    (duplicates of several rows) as well."""
+    N, Q, k = 300_000, 600, 5
+    g = synthetic.unit_rows(N, 512, seed=21)
+    g = g.astype(np.float16).astype(np.float32)          # queries below equal stored rows exactly
+    src = 10 + 50 * np.arange(64)                        # inside the first pass (its rows end in the thousands)
+    dst = 200_000 + 37 * np.arange(64)
+    g[dst] = g[src]
+    for j in range(8):                                   # four more copies of eight rows: all five best tie at 0
+        g[250_000 + 5 * j + np.arange(1, 4)] = g[src[j]]
+        g[2000 + j] = g[src[j]]
+    q = synthetic.unit_rows(Q, 512, seed=22)
+    q[:64] = g[src]
+    gal = Gallery(torch.from_numpy(g), store="f16", device=device)
+    dist, idx = gal.search(torch.from_numpy(q).to(device), k)
+    d, i = dist.cpu().numpy(), idx.cpu().numpy()
+    for j in range(8):
+        want = sorted([int(src[j]), 2000 + j, int(dst[j])] + [250_000 + 5 * j + t for t in (1, 2, 3)])[:k]
+        assert i[j].tolist() == want, (j, i[j], want)
+        assert np.all(d[j] == d[j, 0])
+    for j in range(8, 64):
+        assert i[j, :2].tolist() == [int(src[j]), int(dst[j])], (j, i[j])
+        assert d[j, 0] == d[j, 1]
+    mism, recall = _check_topk(dist[64:], idx[64:], q[64:], g, k, 1e-3)
+    assert recall > 0.98
+    # every returned row is at least as close as the brute force's k-th, so nothing fell below the floor by mistake
+    bd, bi = mref.l2_topk_bruteforce(q[:64], g, k)
+    assert np.abs(d[:64].astype(np.float64) - bd).max() < 1e-3
+    gal.close()
+
+
 def test_gallery_cache_follows_the_tensor_object(device):
     """match_facebank / topk_search keep a device copy per facebank TENSOR OBJECT.  A facebank that is freed
     and replaced by another of the same shape usually gets the same address from the caching allocator
