@@ -300,4 +300,5 @@ def test_bench_line_contract():
         assert cls["bound"] in ("hbm", "mfma") and abs(cls["frac"] - cls["achieved"] / cls["peak"]) < 1e-3
     assert by_class["pointwise_1x1_and_linear"]["bound"] == "mfma" and by_class["depthwise_3x3_and_gdconv"]["bound"] == "hbm"
     rf = r["roofline"]
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == ("GB/s" if rf["bound"] == "hbm" else "TFLOP/s")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
