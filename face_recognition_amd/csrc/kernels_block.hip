@@ -41,6 +41,10 @@
 
 #include "block_stages.h"
 
+#ifndef EPI_CHUNK
+#define EPI_CHUNK 13     // epilogue: shortcut values are requested this many units ahead (13 = all of a 14-row conv_3 band's: -3 % against 4)
+#endif
+
 namespace fra {
 
 template <int CIN, int CEXP, int COUT, int H, int S, int TR, int MODE, int KSPLIT> constexpr int block_lds_bytes();
@@ -381,10 +385,10 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
         // ---- epilogue: accumulators -> f32 pixel rows in LDS -> (+ bias, + shortcut) -> NHWC, 8 bytes per lane -------
         // A thread's units (4 channels of one pixel) are NT apart, i.e. a fixed number of pixels: one base address each
         // for the shortcut, the staging rows and the output, everything else is a compile-time offset.  The shortcut
-        // values are requested a chunk of EPI_CH units ahead, the first chunk before the accumulators are staged, so
-        // their latency runs under the staging pass, its barrier and the previous chunk's stores.
+        // values are requested a chunk of EPI_CH units ahead (with the present shapes: all of a thread's units), the
+        // first chunk before the accumulators are staged, so their latency runs under the staging pass and its barrier.
         constexpr int G = COUT / 4, UNITS = POUT * G;
-        constexpr int EPI_IT = (UNITS + NT - 1) / NT, EPI_CH = 4, EPI_NCH = (EPI_IT + EPI_CH - 1) / EPI_CH;
+        constexpr int EPI_IT = (UNITS + NT - 1) / NT, EPI_CH = EPI_CHUNK, EPI_NCH = (EPI_IT + EPI_CH - 1) / EPI_CH;
         constexpr int PSTEP = NT / G;                          // pixels between two units of a thread
         const int etid = tid;
         const int g = etid % G, p0 = etid / G;

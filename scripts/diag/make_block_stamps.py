@@ -21,7 +21,8 @@ extern "C" int fra_dbg_read(void* dst, size_t bytes) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fra_dbg_stamps), bytes, 0, hipMemcpyDeviceToHost);
 }
 '''
-s = s.replace('#include "common.h"\n', '#include "common.h"\n' + pre, 1)
+assert '#include "block_stages.h"\n' in s
+s = s.replace('#include "block_stages.h"\n', '#include "block_stages.h"\n' + pre, 1)
 def rep(old, new):
     global s
     assert old in s, old
