@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libface_recognition_amd.so")
-SOURCES = ["api.cpp", "kernels_conv.hip", "kernels_gemm.hip", "kernels_block.hip", "kernels_rblock.hip", "kernels_stem.hip", "mfn_model.hip", "fb_search.hip", "ev_fold.hip", "fa_align.hip", "kernels_tail.hip"]
+SOURCES = ["api.cpp", "kernels_conv.hip", "kernels_gemm.hip", "kernels_block.hip", "kernels_rblock.hip", "kernels_pblock.hip", "kernels_stem.hip", "mfn_model.hip", "fb_search.hip", "ev_fold.hip", "fa_align.hip", "kernels_tail.hip"]
 ARCH = "gfx950"
 
 

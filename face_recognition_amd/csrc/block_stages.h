@@ -77,6 +77,53 @@ template <int H, int S> constexpr int block_pitch() {
     return S == 2 ? (H >= 28 ? ((H + 2) | 1) : H + 2) : (H >= 14 ? (H + 2 + 15) / 16 * 16 : H + 2);
 }
 
+// ---- expand stage: LDS reads of one 32-channel tile nt, in issue order: bias quads bq[4], fragments
+// w1[KS1], slope quads sl[4]; the first pixel tile waits with counts, later tiles find the data there ----
+template <typename T, int KS1, int CEXP, int PW1> struct ExpStage {
+    typedef typename vec8<T>::type V8;
+    V8 w1[KS1];
+    f32x4 bq[4], sl[4];
+    int w1l;   // LDS address of this lane's W1 row (+ 16 h); + 32 nt PW1 + 32 ks
+    int pl;    // LDS address of this lane's bias quads of the slice; + 128 nt + 64 (q>>1) + 16 (q&1); slopes CEXP*4 further
+
+    template <int NTI, int I = 0> __device__ __forceinline__ void issue() {
+        if constexpr (I < 4) {
+            LDS_READ16(bq[I], pl, 128 * NTI + 64 * (I >> 1) + 16 * (I & 1));
+            issue<NTI, I + 1>();
+        } else if constexpr (I < 4 + KS1) {
+            LDS_READ16(w1[I - 4], w1l, NTI * 32 * PW1 + (I - 4) * 32);
+            issue<NTI, I + 1>();
+        } else if constexpr (I < 8 + KS1) {
+            constexpr int q = I - 4 - KS1;
+            LDS_READ16(sl[q], pl, CEXP * 4 + 128 * NTI + 64 * (q >> 1) + 16 * (q & 1));
+            issue<NTI, I + 1>();
+        }
+    }
+    // acc = bias + sum_ks w1[ks] . x[ks]
+    template <bool WAIT, int KS = 0> __device__ __forceinline__ void chain(f32x16& acc, const V8 (&x)[KS1]) {
+        if constexpr (KS == 0) {
+            // the four bias quads and fragment 0 have arrived once KS1 - 1 + 4 reads remain
+            if constexpr (WAIT)
+                asm volatile("s_waitcnt lgkmcnt(%5)"
+                             : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(w1[0]) : "n"(KS1 - 1 + 4));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[4 * q + i] = bq[q][i];
+            acc = mfma32(w1[0], x[0], acc);
+            __builtin_amdgcn_sched_barrier(0);             // keep each MFMA right behind its wait
+            chain<WAIT, 1>(acc, x);
+        } else if constexpr (KS < KS1) {
+            if constexpr (WAIT) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w1[KS]) : "n"(KS1 - 1 - KS + 4));
+            acc = mfma32(w1[KS], x[KS], acc);
+            __builtin_amdgcn_sched_barrier(0);
+            chain<WAIT, KS + 1>(acc, x);
+        } else {
+            if constexpr (WAIT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2]), "+v"(sl[3]));
+        }
+    }
+};
+
 // ---- depthwise + project stage of one slice on the matrix cores (issue order above) -----------------
 // Depthwise conv as D[ch][px] = sum over (tap, ch') of Diag[ch][(tap, ch')] . E[(tap, ch')][px] on the SPARSE
 // 16x16x64 MFMA (A is 2:4 structured: per row and group of four k two values and their 2-bit positions; a
@@ -110,6 +157,7 @@ template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ, in
     f32x4 acc[2][NSUB];            // by chunk parity: the next chunk's bias lands while this chunk accumulates
     V8 bf[NSUB];                   // project B operand of the chunk pair, per subtile
     int tb;                        // LDS address of this lane's tap (0, min(g, 2)) in subtile 0; + p ROWB + 32 q (+ 16: second unit) (+ ST1: subtile 1)
+    int tbr[DW_ROWS];              // (ROWB == 0: the window's rows are not a fixed distance apart) that address per window row p
     int w2l;                       // this lane's word of the 3x3 weight image: plane g & 1, position m; + p dw_wrow + 64 q
     int pb;                        // depthwise bias quad of channels 4g..; + 64 q; slopes CEXP*4 further
     int w3l;                       // this lane's project weight row 16 (g & 1) + m, unit g >> 1; + 32 n PW3 + 32 pair
@@ -128,11 +176,12 @@ template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ, in
     template <int ST> __device__ __forceinline__ void issue_taps() {
         constexpr int q = ST / DW_ROWS, p = ST % DW_ROWS;
         constexpr int off = p * ROWB + 32 * q;
-        LDS_READ16(er[ST % DW_RING][0][0], tb, off);
-        LDS_READ16(er[ST % DW_RING][0][1], tb, off + 16);
+        const int base = ROWB ? tb : tbr[p];
+        LDS_READ16(er[ST % DW_RING][0][0], base, off);
+        LDS_READ16(er[ST % DW_RING][0][1], base, off + 16);
         if constexpr (NSUB == 2) {
-            LDS_READ16(er[ST % DW_RING][1][0], tb, ST1 + off);
-            LDS_READ16(er[ST % DW_RING][1][1], tb, ST1 + off + 16);
+            LDS_READ16(er[ST % DW_RING][1][0], base, ST1 + off);
+            LDS_READ16(er[ST % DW_RING][1][1], base, ST1 + off + 16);
         }
     }
     template <int Q, int P> __device__ __forceinline__ void issue_w() { LDS_READ_U32(w[P], w2l, P * dw_wrow(CEXP) + 64 * Q); }

@@ -160,6 +160,10 @@ inline size_t w3_image_index(int co, int pos, int cout) {
     return (((size_t)c * 2 * cout + row) * 4 + unit) * 8 + j;
 }
 int launch_block(int dt, const BlockParams& p, const void* x, void* out, int B, hipStream_t s);
+// the same block as a row pipeline without workgroup-wide barriers (kernels_pblock.hip): same results bit for bit;
+// pblock_has(): the shapes it is built for
+bool pblock_has(const BlockParams& p);
+int launch_pblock(int dt, const BlockParams& p, const void* x, void* out, int B, hipStream_t s);
 
 // ---- residual blocks with the activation kept in registers between blocks (kernels_rblock.hip) ----------------
 // Everything one 64-channel slice of one block needs travels as ONE package, stored in global memory exactly as it

@@ -39,7 +39,13 @@
 // on the host; the project weights are stored as the LDS image of each slice (w3_image_index()).  The two slope arrays hold (PReLU slope - 1):
 // prelu(v) = v + (slope-1) min(v,0).
 
+#include <stdlib.h>
+
 #include "block_stages.h"
+
+#ifndef PBLOCK_MIN_DEFAULT
+#define PBLOCK_MIN_DEFAULT 1000000   // batch from which conv_3 runs as the row pipeline
+#endif
 
 #ifndef EPI_CHUNK
 #define EPI_CHUNK 13     // epilogue: shortcut values are requested this many units ahead (13 = all of a 14-row conv_3 band's: -3 % against 4)
@@ -48,53 +54,6 @@
 namespace fra {
 
 template <int CIN, int CEXP, int COUT, int H, int S, int TR, int MODE, int KSPLIT> constexpr int block_lds_bytes();
-
-// ---- expand stage: LDS reads of one 32-channel tile nt, in issue order: bias quads bq[4], fragments
-// w1[KS1], slope quads sl[4]; the first pixel tile waits with counts, later tiles find the data there ----
-template <typename T, int KS1, int CEXP, int PW1> struct ExpStage {
-    typedef typename vec8<T>::type V8;
-    V8 w1[KS1];
-    f32x4 bq[4], sl[4];
-    int w1l;   // LDS address of this lane's W1 row (+ 16 h); + 32 nt PW1 + 32 ks
-    int pl;    // LDS address of this lane's bias quads of the slice; + 128 nt + 64 (q>>1) + 16 (q&1); slopes CEXP*4 further
-
-    template <int NTI, int I = 0> __device__ __forceinline__ void issue() {
-        if constexpr (I < 4) {
-            LDS_READ16(bq[I], pl, 128 * NTI + 64 * (I >> 1) + 16 * (I & 1));
-            issue<NTI, I + 1>();
-        } else if constexpr (I < 4 + KS1) {
-            LDS_READ16(w1[I - 4], w1l, NTI * 32 * PW1 + (I - 4) * 32);
-            issue<NTI, I + 1>();
-        } else if constexpr (I < 8 + KS1) {
-            constexpr int q = I - 4 - KS1;
-            LDS_READ16(sl[q], pl, CEXP * 4 + 128 * NTI + 64 * (q >> 1) + 16 * (q & 1));
-            issue<NTI, I + 1>();
-        }
-    }
-    // acc = bias + sum_ks w1[ks] . x[ks]
-    template <bool WAIT, int KS = 0> __device__ __forceinline__ void chain(f32x16& acc, const V8 (&x)[KS1]) {
-        if constexpr (KS == 0) {
-            // the four bias quads and fragment 0 have arrived once KS1 - 1 + 4 reads remain
-            if constexpr (WAIT)
-                asm volatile("s_waitcnt lgkmcnt(%5)"
-                             : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(w1[0]) : "n"(KS1 - 1 + 4));
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[4 * q + i] = bq[q][i];
-            acc = mfma32(w1[0], x[0], acc);
-            __builtin_amdgcn_sched_barrier(0);             // keep each MFMA right behind its wait
-            chain<WAIT, 1>(acc, x);
-        } else if constexpr (KS < KS1) {
-            if constexpr (WAIT) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w1[KS]) : "n"(KS1 - 1 - KS + 4));
-            acc = mfma32(w1[KS], x[KS], acc);
-            __builtin_amdgcn_sched_barrier(0);
-            chain<WAIT, KS + 1>(acc, x);
-        } else {
-            if constexpr (WAIT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2]), "+v"(sl[3]));
-        }
-    }
-};
 
 template <typename T, int CIN, int CEXP, int COUT, int H, int S, int TR, bool RESID, int NW, int MINW, int MODE, int KSPLIT>
 __global__ __launch_bounds__(NW * 64, MINW)
@@ -564,6 +523,10 @@ int launch_block(int dt, const BlockParams& p, const void* x, void* out, int B, 
     const bool is_res_cfg = (p.stride == 1);
     FRA_REQUIRE(want_res == is_res_cfg, FRA_ERR_ARG, "block: stride %d with residual=%d has no fused kernel", p.stride,
                 p.residual);
+    // whole-image workgroups of the row pipeline once every compute unit gets an image (FRA_PBLOCK_MIN=<batch> moves
+    // the limit, 0 turns the pipeline off: for measurements)
+    static const int pb_min = [] { const char* e = getenv("FRA_PBLOCK_MIN"); return e ? atoi(e) : -1; }();
+    if (pblock_has(p) && pb_min != 0 && B >= (pb_min > 0 ? pb_min : PBLOCK_MIN_DEFAULT)) return launch_pblock(dt, p, x, out, B, s);
     if (dt == ACT_F16) return launch_block_t<f16>(p, x, out, B, s);
     if (dt == ACT_BF16) return launch_block_t<bf16>(p, x, out, B, s);
     FRA_REQUIRE(false, FRA_ERR_ARG, "block: unsupported activation dtype %d", dt);

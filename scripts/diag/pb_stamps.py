@@ -1,0 +1,28 @@
+"""Where the waves of the row-pipeline kernel (kernels_pblock.hip built with -DPB_STAMPS) spend their cycles:
+python scripts/diag/pb_stamps.py [batch] [producer waves]   (FRA_PBLOCK_MIN must select the kernel for that batch)"""
+import ctypes as C, sys, numpy as np, torch
+sys.path.insert(0, ".")
+from face_recognition_amd import _lib, synthetic
+from face_recognition_amd.face_model import MobileFaceNet
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+NP = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+net = MobileFaceNet(512)
+net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(1, 512).items()})
+net = net.to("cuda:0").eval()
+x = torch.randn(B, 3, 112, 112, device="cuda:0")
+for _ in range(3):
+    net.debug_prefix(x, 3)          # stem, conv_23, conv_3 block 0: the last launch is the pipeline kernel
+torch.cuda.synchronize()
+lib = _lib.load()
+lib.fra_dbg_read.restype = C.c_int
+lib.fra_dbg_read.argtypes = [C.c_void_p, C.c_size_t]
+nwg = min(B, 256)
+buf = np.zeros((nwg, 8, 8), dtype=np.uint64)
+assert lib.fra_dbg_read(buf.ctypes.data, buf.nbytes) == 0
+c = buf.astype(np.float64)
+print("median cycles per wave over %d workgroups (kernel total %.0f)" % (nwg, np.median(c[:, :, 7])))
+for w in range(8):
+    role = "producer" if w < NP else "consumer"
+    names = ("wait for ring space", "expand + flag", "fragment move") if w < NP else ("wait for rows", "depthwise + project", "epilogue")
+    m = np.median(c[:, w, :], axis=0)
+    print("  wave %d %s: %s" % (w, role, ", ".join("%s %.0f" % (n, v) for n, v in zip(names, m[:3]))), " total %.0f" % m[7])
