@@ -56,13 +56,16 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_label(name, kind, dt):
-    """Name of the device kernel an op runs, as rocprofv3 prints it (template arguments included)."""
+def kernel_label(name, kind, dt, variant=0):
+    """Name of the device kernel an op runs, as rocprofv3 prints it (leading template arguments included);
+    variant: what the library says it launches for this batch (MobileFaceNet.op_variants)."""
     T = "_Float16" if dt == "f16" else "__bf16"
     if kind == "block":
         b = next(b for b in layers.BLOCKS if b.prefix == name)
-        if name.startswith("conv_4."):
+        if variant == 1:
             return f"rblock_kernel<{T}, {b.cin}, {b.cexp}, {b.hin}>"
+        if variant == 2:
+            return f"pblock_kernel<{T}, {b.cin}, {b.cexp}, {b.cout}, {b.hin}>"
         return f"block_kernel<{T}, {b.cin}, {b.cexp}, {b.cout}, {b.hin}, {b.stride}>"
     for c in layers.all_convs():
         if c.prefix == name:
@@ -87,9 +90,10 @@ def per_kernel_profile(net, x, reps, dt):
     ms = acc / reps
     B = x.shape[0]
     plan = net.launch_plan(B)       # op -> the op whose launch covers it (a chain of blocks is one launch)
+    variants = net.op_variants(B)
     groups = {}
     for i, ((name, kind, flops, nbytes, wbytes), t) in enumerate(zip(table, ms)):
-        g = groups.setdefault(kernel_label(name, kind, dt), dict(kind=kind, launches=0, ops=0, ms=0.0, bytes=0.0, flops=0.0))
+        g = groups.setdefault(kernel_label(name, kind, dt, variants[i]), dict(kind=kind, launches=0, ops=0, ms=0.0, bytes=0.0, flops=0.0))
         g["ops"] += 1
         g["ms"] += float(t)
         g["flops"] += flops * B

@@ -38,6 +38,7 @@ SIGNATURES = {
     "mfn_workspace_bytes_ex": (_I, [_P, _I, _I, C.POINTER(C.c_size_t)]),
     "mfn_forward_timed": (_I, [_P, _P, _I, _P, _P, C.c_size_t, _P, C.POINTER(C.c_float), _I]),
     "mfn_op_count": (_I, [_P]),
+    "mfn_op_variant": (_I, [_P, _I, _I]),
     "mfn_op_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_I), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
     "mfn_debug_prefix": (_I, [_P, _P, _I, _I, _P, C.POINTER(_L), _P, C.c_size_t, _P]),
     "mfn_destroy": (_I, [_P]),

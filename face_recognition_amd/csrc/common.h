@@ -161,8 +161,11 @@ inline size_t w3_image_index(int co, int pos, int cout) {
 }
 int launch_block(int dt, const BlockParams& p, const void* x, void* out, int B, hipStream_t s);
 // the same block as a row pipeline without workgroup-wide barriers (kernels_pblock.hip): same results bit for bit;
-// pblock_has(): the shapes it is built for
+// pblock_has(): the shapes it is built for; pblock_pays(): whether it is the faster of the two for a batch of B images
 bool pblock_has(const BlockParams& p);
+bool pblock_pays(const BlockParams& p, int B);
+// what launch_block() does with a batch of B images: true = the row pipeline
+bool block_uses_pipeline(const BlockParams& p, int B);
 int launch_pblock(int dt, const BlockParams& p, const void* x, void* out, int B, hipStream_t s);
 
 // ---- residual blocks with the activation kept in registers between blocks (kernels_rblock.hip) ----------------

@@ -43,9 +43,6 @@
 
 #include "block_stages.h"
 
-#ifndef PBLOCK_MIN_DEFAULT
-#define PBLOCK_MIN_DEFAULT 1000000   // batch from which conv_3 runs as the row pipeline
-#endif
 
 #ifndef EPI_CHUNK
 #define EPI_CHUNK 13     // epilogue: shortcut values are requested this many units ahead (13 = all of a 14-row conv_3 band's: -3 % against 4)
@@ -515,6 +512,13 @@ static int launch_block_t(const BlockParams& p, const void* x, void* out, int B,
     return FRA_ERR_ARG;
 }
 
+// conv_3 runs as the row pipeline of kernels_pblock.hip where that is the faster one (FRA_PBLOCK_MIN=<batch>: from that
+// batch on instead, 0: never -- for measurements)
+bool block_uses_pipeline(const BlockParams& p, int B) {
+    static const int pb_min = [] { const char* e = getenv("FRA_PBLOCK_MIN"); return e ? atoi(e) : -1; }();
+    return pb_min < 0 ? pblock_pays(p, B) : (pb_min > 0 && pblock_has(p) && B >= pb_min);
+}
+
 int launch_block(int dt, const BlockParams& p, const void* x, void* out, int B, hipStream_t s) {
     FRA_REQUIRE(x && out && p.w1 && p.b1p && p.s1p && p.w2p && p.b2p && p.s2p && p.w3p && p.b3, FRA_ERR_ARG,
                 "block: null pointer");
@@ -523,10 +527,7 @@ int launch_block(int dt, const BlockParams& p, const void* x, void* out, int B, 
     const bool is_res_cfg = (p.stride == 1);
     FRA_REQUIRE(want_res == is_res_cfg, FRA_ERR_ARG, "block: stride %d with residual=%d has no fused kernel", p.stride,
                 p.residual);
-    // whole-image workgroups of the row pipeline once every compute unit gets an image (FRA_PBLOCK_MIN=<batch> moves
-    // the limit, 0 turns the pipeline off: for measurements)
-    static const int pb_min = [] { const char* e = getenv("FRA_PBLOCK_MIN"); return e ? atoi(e) : -1; }();
-    if (pblock_has(p) && pb_min != 0 && B >= (pb_min > 0 ? pb_min : PBLOCK_MIN_DEFAULT)) return launch_pblock(dt, p, x, out, B, s);
+    if (block_uses_pipeline(p, B)) return launch_pblock(dt, p, x, out, B, s);
     if (dt == ACT_F16) return launch_block_t<f16>(p, x, out, B, s);
     if (dt == ACT_BF16) return launch_block_t<bf16>(p, x, out, B, s);
     FRA_REQUIRE(false, FRA_ERR_ARG, "block: unsupported activation dtype %d", dt);

@@ -51,7 +51,7 @@ extern "C" int fra_dbg_read(void* dst, size_t bytes) {
 #endif
 
 #ifndef PB_SPIN_LIMIT
-#define PB_SPIN_LIMIT (1 << 16)   // polls after which a wait gives up (wrong results instead of a wave that never ends)
+#define PB_SPIN_LIMIT (1 << 20)   // polls (some 0.1 s) after which a wait gives up: wrong results instead of a wave that never ends
 #endif
 
 template <typename T, int CIN, int CEXP, int COUT, int H, int NP, int NC, int NR>
@@ -68,7 +68,7 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
     constexpr int SLOT = L::SLOT, ROWB = L::ROWB, PW1 = L::PW1, PW3 = L::PW3;
     constexpr int NI1 = L::W1_BYTES / 1024, NI3 = L::W3_BYTES / 1024;
     static_assert(L::W1_BYTES % 1024 == 0 && L::W3_BYTES % 1024 == 0, "weight images are whole DMA pieces");
-    static_assert(NR >= NC + 3, "ring rows: the windows of all consumers and one row being written");
+    static_assert(NR >= (NP > 0 ? NC + 3 : NW + 3), "ring rows: the windows of all consumers and one row being written");
     static_assert(W <= 28 && W > 16, "a row is one 32-lane tile: two 16-pixel subtiles");
     static_assert(CIN == COUT && CEXP % 64 == 0 && NC <= 8, "shape");
     static_assert(L::BYTES <= 160 * 1024, "LDS budget");
@@ -118,7 +118,7 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
     // ring + zero row + slack: border slots stay zero for ever, everything a lane may read is a finite value
     for (int i = tid; i < L::OFF_WB / 16; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < NR) ready[tid] = 0;
-    if (tid < 8) progress[tid] = tid < NC ? tid - NC : 0x3fffffff;
+    if (tid < 8) progress[tid] = tid < (NP > 0 ? NC : NW) ? tid - (NP > 0 ? NC : NW) : 0x3fffffff;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -129,164 +129,183 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
     const int nimg = (B - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
     const int NG = nimg * H;                               // rows this workgroup handles, numbered through
 
-    if (wave < NP) {
-        // ================= producer: expand row G into ring slot G % NR =================
-        const int r = lane & 31, h = lane >> 5;
-        const int px = r < W ? r : W - 1;                  // lanes past the row end load a valid pixel and write nothing
-        const int wr = r < W ? (r + 1) * SLOT + 16 * h : -1;
-        V8 xf[KS1], xn[KS1];
-        auto row_ptr = [&](int G) {
-            const int k = G / H, y = G - k * H;
-            return X + ((size_t)((int)blockIdx.y + k * (int)gridDim.y) * H * W + (size_t)y * W + px) * CIN + 8 * h;
-        };
-        if (wave < NG) {
-            const T* p0 = row_ptr(wave);
+    // ================= produce: expand row G into ring slot G % NR =================
+    constexpr int NCONS = NP > 0 ? NC : NW;                // waves that consume rows (their progress words)
+    const int r = lane & 31, h = lane >> 5;
+    const int px = r < W ? r : W - 1;                      // lanes past the row end load a valid pixel and write nothing
+    const int wr = r < W ? (r + 1) * SLOT + 16 * h : -1;
+    V8 xf[KS1], xn[KS1];                                   // input fragments of the row to expand, and of the one after it
+    auto load_row = [&](V8 (&dst)[KS1], int G) {
+        const int k = G / H, y = G - k * H;
+        const T* ptr = X + ((size_t)((int)blockIdx.y + k * (int)gridDim.y) * H * W + (size_t)y * W + px) * CIN + 8 * h;
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) xf[ks] = *reinterpret_cast<const V8*>(p0 + 16 * ks);
+        for (int ks = 0; ks < KS1; ++ks) dst[ks] = *reinterpret_cast<const V8*>(ptr + 16 * ks);
+    };
+    typedef ExpStage<T, KS1, CEXP, PW1> Ex;
+    // xf holds row G's fragments; Gnext (if < NG) is the row this wave expands next: requested now, moved over at the end
+    auto produce = [&](int G, int Gnext) {
+        if (Gnext < NG) load_row(xn, Gnext);
+        PB_T(t0);
+        if (G >= NR) {
+            // slot G % NR holds row G - NR, read for output rows up to G - NR + 1: every consumer must be past them
+            const int need = G - NR - NCONS + 2;
+            for (int spin = 0; spin < PB_SPIN_LIMIT; ++spin) {
+                const int v = progress[lane & 7];
+                if (__builtin_amdgcn_ballot_w64(v < need) == 0) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
         }
-        typedef ExpStage<T, KS1, CEXP, PW1> Ex;
-        for (int G = wave; G < NG; G += NP) {
-            if (G + NP < NG) {
-                const T* pn = row_ptr(G + NP);
+        asm volatile("" ::: "memory");
+        PB_T(t1);
+        PB_ACC(0, t0, t1);
+        char* rowl = lds + (G % NR) * ROWB;
+        static_for<NCH>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            static_for<2>([&](auto ntc) {
+                constexpr int nt = decltype(ntc)::value;
+                Ex ex;
+                ex.w1l = L::OFF_WB + c * L::WB_BYTES + r * PW1 + 16 * h;
+                ex.pl = L::OFF_B1 + 256 * c + 32 * h;
+                ex.template issue<nt>();
+                f32x16 acc;
+                ex.template chain<true>(acc, xf);
+                if (wr >= 0) {
 #pragma unroll
-                for (int ks = 0; ks < KS1; ++ks) xn[ks] = *reinterpret_cast<const V8*>(pn + 16 * ks);
-            }
-            PB_T(t0);
-            if (G >= NR) {
-                // slot G % NR holds row G - NR, read for output rows up to G - NR + 1: every consumer must be past them
-                const int need = G - NR - NC + 2;
-                for (int spin = 0; spin < PB_SPIN_LIMIT; ++spin) {
-                    const int v = progress[lane & 7];
-                    if (__builtin_amdgcn_ballot_w64(v < need) == 0) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            asm volatile("" ::: "memory");
-            PB_T(t1);
-            PB_ACC(0, t0, t1);
-            char* rowl = lds + (G % NR) * ROWB;
-            static_for<NCH>([&](auto cc) {
-                constexpr int c = decltype(cc)::value;
-                static_for<2>([&](auto ntc) {
-                    constexpr int nt = decltype(ntc)::value;
-                    Ex ex;
-                    ex.w1l = L::OFF_WB + c * L::WB_BYTES + r * PW1 + 16 * h;
-                    ex.pl = L::OFF_B1 + 256 * c + 32 * h;
-                    ex.template issue<nt>();
-                    f32x16 acc;
-                    ex.template chain<true>(acc, xf);
-                    if (wr >= 0) {
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        V8 o;
 #pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            V8 o;
+                        for (int a = 0; a < 2; ++a) {
+                            const int q = 2 * s2 + a;
 #pragma unroll
-                            for (int a = 0; a < 2; ++a) {
-                                const int q = 2 * s2 + a;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    const float v = acc[4 * q + i];
-                                    o[4 * a + i] = (T)fmaf(neg_part(v), ex.sl[q][i], v);   // PReLU: sl = slope - 1
-                                }
+                            for (int i = 0; i < 4; ++i) {
+                                const float v = acc[4 * q + i];
+                                o[4 * a + i] = (T)fmaf(neg_part(v), ex.sl[q][i], v);   // PReLU: sl = slope - 1
                             }
-                            *reinterpret_cast<V8*>(rowl + wr + 128 * c + (2 * nt + s2) * 32) = o;
                         }
+                        *reinterpret_cast<V8*>(rowl + wr + 128 * c + (2 * nt + s2) * 32) = o;
                     }
-                });
-            });
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the row is in LDS before its flag goes up
-            if (lane == 0) ready[G % NR] = G + 1;
-            PB_T(t2);
-            PB_ACC(1, t1, t2);
-            if (G + NP < NG) {
-#pragma unroll
-                for (int ks = 0; ks < KS1; ++ks) xf[ks] = xn[ks];
-            }
-            PB_T(t3);
-            PB_ACC(2, t2, t3);
-        }
-    } else {
-        // ================= consumer: output row G from ring rows G - 1, G, G + 1 =================
-        const int cw = wave - NP;
-        const int m16 = lane & 15, g4 = lane >> 4;
-        constexpr int ST1 = 16 * SLOT;
-        const int lpart = (m16 + (g4 < 2 ? g4 : 2)) * SLOT;    // this lane's tap (., min(g, 2)) of subtile 0 inside a row
-        const bool ok1 = m16 + 16 < W;                         // subtile 1: columns 16 ..
-        f32x4 b3q[NT16];
-#pragma unroll
-        for (int n = 0; n < NT16; ++n) b3q[n] = *reinterpret_cast<const f32x4*>(b3 + 16 * n + 4 * g4);
-        for (int G = cw; G < NG; G += NC) {
-            const int k = G / H, y = G - k * H;
-            const size_t pix = ((size_t)((int)blockIdx.y + k * (int)gridDim.y) * H + y) * W;
-            const T* xs = X + (pix + m16) * CIN + 4 * g4;
-            T* os = O + (pix + m16) * COUT + 4 * g4;
-            // shortcut values: channels 16 n + 4 g .. of this lane's pixel, per subtile
-            V4 rr[2][NT16];
-#pragma unroll
-            for (int n = 0; n < NT16; ++n) {
-                rr[0][n] = *reinterpret_cast<const V4*>(xs + 16 * n);
-                if (ok1) rr[1][n] = *reinterpret_cast<const V4*>(xs + 16 * CIN + 16 * n);
-            }
-            // wait for the window's rows (those inside the image)
-            PB_T(t0);
-            {
-                const int d = (lane % 3) - 1, yy = y + d;
-                const bool inside = yy >= 0 && yy < H;
-                const int idx = (G + d + NR) % NR, want = G + d + 1;
-                for (int spin = 0; spin < PB_SPIN_LIMIT; ++spin) {
-                    const int v = ready[idx];
-                    if (__builtin_amdgcn_ballot_w64(inside && v < want) == 0) break;
-                    __builtin_amdgcn_s_sleep(1);
                 }
-            }
-            asm volatile("" ::: "memory");
-            PB_T(t1);
-            PB_ACC(0, t0, t1);
-            int rowb[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const int yy = y - 1 + p;
-                rowb[p] = (yy >= 0 && yy < H ? ((G - 1 + p + NR) % NR) * ROWB : L::OFF_ZERO) + lpart;
-            }
-            f32x4 pacc[2][NT16];
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int n = 0; n < NT16; ++n) pacc[st][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-            static_for<NCH>([&](auto cc) {
-                constexpr int c = decltype(cc)::value;
-                DwStage<T, CEXP, NT16, PW3, ST1, 0, 4, 2> dw;
-                dw.set_lane(m16, g4);
-#pragma unroll
-                for (int p = 0; p < 3; ++p) dw.tbr[p] = rowb[p] + 128 * c;
-                dw.w2l = L::OFF_W2 + (g4 & 1) * dw_wplane(CEXP) + (64 * c + m16) * 4;
-                dw.pb = L::OFF_B2 + 256 * c + 16 * g4;
-                dw.w3l = L::OFF_WB + c * L::WB_BYTES + L::W1_BYTES + (16 * (g4 & 1) + m16) * PW3 + 16 * (g4 >> 1);
-                dw.preamble();
-                dw.run(pacc);
             });
-            asm volatile("" ::: "memory");
-            if (lane == 0) progress[cw] = G;               // every read of the window has returned
-            PB_T(t2);
-            PB_ACC(1, t1, t2);
-            // epilogue in registers: (acc + x) + b3, channel for channel what the lane holds
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the row is in LDS before its flag goes up
+        if (lane == 0) ready[G % NR] = G + 1;
+        PB_T(t2);
+        PB_ACC(1, t1, t2);
+        if (Gnext < NG) {
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) xf[ks] = xn[ks];
+        }
+    };
+
+    // ================= consume: output row G from ring rows G - 1, G, G + 1 =================
+    const int m16 = lane & 15, g4 = lane >> 4;
+    constexpr int ST1 = 16 * SLOT;
+    const int lpart = (m16 + (g4 < 2 ? g4 : 2)) * SLOT;    // this lane's tap (., min(g, 2)) of subtile 0 inside a row
+    const bool ok1 = m16 + 16 < W;                         // subtile 1: columns 16 ..
+    f32x4 b3q[NT16];
+#pragma unroll
+    for (int n = 0; n < NT16; ++n) b3q[n] = *reinterpret_cast<const f32x4*>(b3 + 16 * n + 4 * g4);
+    auto consume = [&](int G, int cw) {                    // cw: this wave's progress word
+        const int k = G / H, y = G - k * H;
+        const size_t pix = ((size_t)((int)blockIdx.y + k * (int)gridDim.y) * H + y) * W;
+        const T* xs = X + (pix + m16) * CIN + 4 * g4;
+        T* os = O + (pix + m16) * COUT + 4 * g4;
+        // shortcut values: channels 16 n + 4 g .. of this lane's pixel, per subtile
+        V4 rr[2][NT16];
+#pragma unroll
+        for (int n = 0; n < NT16; ++n) {
+            rr[0][n] = *reinterpret_cast<const V4*>(xs + 16 * n);
+            if (ok1) rr[1][n] = *reinterpret_cast<const V4*>(xs + 16 * CIN + 16 * n);
+        }
+        // wait for the window's rows (those inside the image)
+        PB_T(t0);
+        {
+            const int d = (lane % 3) - 1, yy = y + d;
+            const bool inside = yy >= 0 && yy < H;
+            const int idx = (G + d + NR) % NR, want = G + d + 1;
+            for (int spin = 0; spin < PB_SPIN_LIMIT; ++spin) {
+                const int v = ready[idx];
+                if (__builtin_amdgcn_ballot_w64(inside && v < want) == 0) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        asm volatile("" ::: "memory");
+        PB_T(t1);
+        PB_ACC(3, t0, t1);
+        int rowb[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int yy = y - 1 + p;
+            rowb[p] = (yy >= 0 && yy < H ? ((G - 1 + p + NR) % NR) * ROWB : L::OFF_ZERO) + lpart;
+        }
+        f32x4 pacc[2][NT16];
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int n = 0; n < NT16; ++n) pacc[st][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        static_for<NCH>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            DwStage<T, CEXP, NT16, PW3, ST1, 0, 4, 2> dw;
+            dw.set_lane(m16, g4);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) dw.tbr[p] = rowb[p] + 128 * c;
+            dw.w2l = L::OFF_W2 + (g4 & 1) * dw_wplane(CEXP) + (64 * c + m16) * 4;
+            dw.pb = L::OFF_B2 + 256 * c + 16 * g4;
+            dw.w3l = L::OFF_WB + c * L::WB_BYTES + L::W1_BYTES + (16 * (g4 & 1) + m16) * PW3 + 16 * (g4 >> 1);
+            dw.preamble();
+            dw.run(pacc);
+        });
+        asm volatile("" ::: "memory");
+        if (lane == 0) progress[cw] = G;                   // every read of the window has returned
+        PB_T(t2);
+        PB_ACC(4, t1, t2);
+        // epilogue in registers: (acc + x) + b3, channel for channel what the lane holds
+#pragma unroll
+        for (int n = 0; n < NT16; ++n) {
+            V4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (T)((pacc[0][n][i] + (float)rr[0][n][i]) + b3q[n][i]);
+            *reinterpret_cast<V4*>(os + 16 * n) = o;
+        }
+        if (ok1) {
 #pragma unroll
             for (int n = 0; n < NT16; ++n) {
                 V4 o;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (T)((pacc[0][n][i] + (float)rr[0][n][i]) + b3q[n][i]);
-                *reinterpret_cast<V4*>(os + 16 * n) = o;
+                for (int i = 0; i < 4; ++i) o[i] = (T)((pacc[1][n][i] + (float)rr[1][n][i]) + b3q[n][i]);
+                *reinterpret_cast<V4*>(os + 16 * COUT + 16 * n) = o;
             }
-            if (ok1) {
-#pragma unroll
-                for (int n = 0; n < NT16; ++n) {
-                    V4 o;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (T)((pacc[1][n][i] + (float)rr[1][n][i]) + b3q[n][i]);
-                    *reinterpret_cast<V4*>(os + 16 * COUT + 16 * n) = o;
-                }
+        }
+        PB_T(t3);
+        PB_ACC(5, t2, t3);
+    };
+
+    if constexpr (NP > 0) {
+        // fixed roles: waves 0 .. NP-1 produce rows p, p + NP, ..., the others consume rows c, c + NC, ...
+        if (wave < NP) {
+            if (wave < NG) load_row(xf, wave);
+            for (int G = wave; G < NG; G += NP) produce(G, G + NP);
+        } else {
+            for (int G = wave - NP; G < NG; G += NC) consume(G, wave - NP);
+        }
+    } else {
+        // every wave alternates: in round i it expands row NW i + w and computes output row NW i + w - 2 (the rows it
+        // needs, up to NW i + w - 1, come from the same round's earlier half).  The lower half of the waves expands first
+        // and computes second, the upper half the other way round (computing the previous round's row first), so the
+        // two waves of a SIMD (w and w + NW / 2) do different kinds of work at any time.
+        const int ph = wave >= NW / 2 ? 1 : 0;
+        const int cw = (wave + NW - 2) % NW;               // rows NW i + w - 2 are the rows cw, cw + NW, ...
+        if (wave < NG) load_row(xf, wave);
+        const int rounds = (NG + NW - 1) / NW + 2;
+        for (int t = 0; t < 2 * rounds; ++t) {
+            const int i = t >> 1;
+            if (((t + ph) & 1) == 0) {
+                const int G = NW * i + wave;
+                if (G < NG) produce(G, G + NW);
+            } else {
+                const int G = NW * (i - ph) + wave - 2;
+                if (G >= 0 && G < NG) consume(G, cw);
             }
-            PB_T(t3);
-            PB_ACC(2, t2, t3);
         }
     }
 #ifdef PB_STAMPS
@@ -304,27 +323,42 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
 #ifndef PB_NR
 #define PB_NR 10
 #endif
+static int pb_compute_units() {
+    static std::atomic<int> cus_of[64];        // compute units per device (0 = not asked yet)
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev < 64 && (cus = cus_of[dev].load(std::memory_order_relaxed)) > 0) return cus;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (dev < 64) cus_of[dev].store(cus, std::memory_order_relaxed);
+    return cus;
+}
+
 template <typename T, int CIN, int CEXP, int COUT, int H>
 static int launch_pblock_cfg(const BlockParams& p, const void* x, void* out, int B, hipStream_t s) {
-    constexpr int NP = PB_NP, NC = 8 - NP, NR = PB_NR;
+    constexpr int NP = PB_NP, NC = 8 - NP, NR = PB_NR;    // NP == 0: every wave expands and computes in turn
     constexpr int lds = PbLds<CIN, CEXP, COUT, H, NR>::BYTES;
     auto kern = pblock_kernel<T, CIN, CEXP, COUT, H, NP, NC, NR>;
     static std::atomic<uint64_t> lds_set;      // per instantiation: devices whose LDS limit is raised
-    static std::atomic<int> cus_of[64];        // compute units per device (0 = not asked yet)
-    int dev = 0;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set, &dev)) return rc;
-    int cus = dev < 64 ? cus_of[dev].load(std::memory_order_relaxed) : 0;
-    if (cus == 0) {
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        if (dev < 64) cus_of[dev].store(cus, std::memory_order_relaxed);
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set)) return rc;
     // one workgroup per compute unit (LDS), each walking over its images in equal shares
+    const int cus = pb_compute_units();
     const int per = (B + cus - 1) / cus;
     const int groups = (B + per - 1) / per;
     hipLaunchKernelGGL(kern, dim3(1, groups), dim3((NP + NC) * 64), lds, s, (const T*)x, (const T*)p.w1, p.b1p, p.s1p,
                        (const T*)p.w2p, p.b2p, p.s2p, (const T*)p.w3p, p.b3, (T*)out, B);
     FRA_HIP(hipGetLastError());
     return FRA_OK;
+}
+
+// A pipeline workgroup owns whole images: k = ceil(B / CUs) images one after the other, about 9 + 20.6 k microseconds
+// measured on 256 compute units, against 7 + 0.0906 B for the band kernels, whose bands fill the chip at any batch.  The
+// pipeline wins where the batch is a little under a multiple of the compute-unit count (250-256, 477-512, 704-768,
+// 931-1024 images, ...).
+bool pblock_pays(const BlockParams& p, int B) {
+    if (!pblock_has(p)) return false;
+    const int cus = pb_compute_units();
+    const int64_t k = (B + cus - 1) / cus;
+    return (int64_t)B * 256 > (227 * k + 22) * cus;
 }
 
 bool pblock_has(const BlockParams& p) {

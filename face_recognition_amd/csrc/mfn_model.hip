@@ -722,6 +722,15 @@ int mfn_forward_timed(mfn_handle* h, const float* x, int B, float* out, void* ws
 
 int mfn_op_count(const mfn_handle* h) { return h ? (int)h->ops().size() : -1; }
 
+int mfn_op_variant(const mfn_handle* h, int op, int B) {
+    FRA_REQUIRE(h && op >= 0 && op < (int)h->ops().size() && B > 0, FRA_ERR_ARG, "mfn_op_variant: bad argument");
+    const Op& o = h->ops()[op];
+    if (o.kind != OP_BLOCK) return 0;
+    if (o.rblock) return 1;
+    FRA_DEVICE(h->device);
+    return block_uses_pipeline(o.bp, B) ? 2 : 0;
+}
+
 int mfn_op_info(const mfn_handle* h, int op, char* name, int name_cap, int* kind, double* flops, double* bytes,
                 double* weight_bytes) {
     FRA_REQUIRE(h && op >= 0 && op < (int)h->ops().size(), FRA_ERR_ARG, "mfn_op_info: bad argument");

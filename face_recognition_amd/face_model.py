@@ -308,6 +308,20 @@ class MobileFaceNet(nn.Module):
             rows.append((name.value.decode(), kinds[kind.value], fl.value, by.value, wb.value))
         return rows
 
+    def op_variants(self, batch: int):
+        """For every op of op_table(): 0 = the kernel of its kind, 1 = rblock_kernel, 2 = pblock_kernel (the row
+        pipeline) -- what a batch of ``batch`` crops runs."""
+        lib = _lib.load()
+        if self._handle is None:
+            raise RuntimeError("op_variants: run a forward first")
+        out = []
+        for i in range(lib.mfn_op_count(self._handle)):
+            v = lib.mfn_op_variant(self._handle, i, int(batch))
+            if v < 0:
+                _lib.check(v, "mfn_op_variant")
+            out.append(v)
+        return out
+
     def debug_prefix(self, x: torch.Tensor, n_ops: int) -> torch.Tensor:
         """Activation after the first ``n_ops`` kernels as f32 NHWC [B,H,W,C] (test helper)."""
         x = self._check_input(x)

@@ -99,6 +99,10 @@ int mfn_workspace_bytes_ex(const mfn_handle* h, int max_batch, int tta, size_t* 
 int mfn_forward_timed(mfn_handle* h, const float* x_nchw, int B, float* out, void* workspace,
                       size_t workspace_bytes, fra_stream stream, float* op_ms, int n_ops);
 int mfn_op_count(const mfn_handle* h);
+/* Which device kernel runs op `op` in a batch of B images (for benchmark labels; no counterpart in the reference):
+ * 0 = the kernel of its kind (block_kernel for a fused block), 1 = rblock_kernel (residual blocks whose activation stays in
+ * registers), 2 = pblock_kernel (the block as a row pipeline inside a workgroup).  Negative: an error code. */
+int mfn_op_variant(const mfn_handle* h, int op, int B);
 /* kind: 0 stem, 1 depthwise 3x3, 2 pointwise, 3 gdconv 7x7, 4 linear+l2norm, 5 fused block, 6 fused stem + first depthwise,
  * 7 fused tail (conv_6_sep + conv_6_dw).  flops / bytes are the
  * algorithmic work and HBM traffic (activations read + written) of the op for ONE image; weight_bytes

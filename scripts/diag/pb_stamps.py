@@ -21,8 +21,7 @@ buf = np.zeros((nwg, 8, 8), dtype=np.uint64)
 assert lib.fra_dbg_read(buf.ctypes.data, buf.nbytes) == 0
 c = buf.astype(np.float64)
 print("median cycles per wave over %d workgroups (kernel total %.0f)" % (nwg, np.median(c[:, :, 7])))
+names = ("wait for ring space", "expand + flag", "-", "wait for rows", "depthwise + project", "epilogue")
 for w in range(8):
-    role = "producer" if w < NP else "consumer"
-    names = ("wait for ring space", "expand + flag", "fragment move") if w < NP else ("wait for rows", "depthwise + project", "epilogue")
     m = np.median(c[:, w, :], axis=0)
-    print("  wave %d %s: %s" % (w, role, ", ".join("%s %.0f" % (n, v) for n, v in zip(names, m[:3]))), " total %.0f" % m[7])
+    print("  wave %d: %s" % (w, ", ".join("%s %.0f" % (n, v) for n, v in zip(names, m[:6]) if n != "-")), " total %.0f" % m[7])

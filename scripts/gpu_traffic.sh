@@ -23,7 +23,9 @@ def label(k):
     # demangled or mangled kernel name -> the label bench.py prints
     m = re.search(r"rblock_kernelIDF16_Li(\d+)ELi(\d+)ELi(\d+)E", k)
     if m: return "rblock_kernel<_Float16, %s, %s, %s>" % m.groups()
-    m = re.search(r"[^r]block_kernelIDF16_Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", k)
+    m = re.search(r"pblock_kernelIDF16_Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", k)
+    if m: return "pblock_kernel<_Float16, %s, %s, %s, %s>" % m.groups()
+    m = re.search(r"[^rp]block_kernelIDF16_Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", k)
     if m: return "block_kernel<_Float16, %s, %s, %s, %s, %s>" % m.groups()
     for key, lab in (("stemdw_kernelIDF16_", "stemdw_kernel<_Float16>"), ("pw_gemm_kernelIDF16_Li128ELi128ELi2E", "pw_gemm_kernel<_Float16, 128, 128, 2>"),
                      ("gdconv7_kernelIDF16_", "gdconv7_kernel<_Float16>"), ("tail_kernelIDF16_", "tail_kernel<_Float16>"), ("linear_l2norm_kernelIDF16_Li16ELi1E", "linear_l2norm_kernel<_Float16, 16, 1>")):

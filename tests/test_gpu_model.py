@@ -123,6 +123,26 @@ def test_chained_and_per_block_launches_agree_bit_for_bit(hip_model, device):
     assert torch.equal(hip_model(x[:60].contiguous()).cpu(), want[:60])  # 7-row bands
 
 
+def test_row_pipeline_kernel_matches_band_kernels(device, hip_model, state_dict_np):
+    """conv_3 runs as a row pipeline inside a workgroup (producer / consumer waves, flags in LDS, no workgroup-wide
+    barriers) where a batch is just under a multiple of the compute-unit count, as band kernels elsewhere; both give
+    the same bits.  512 crops: pipeline, two images per workgroup; 256: pipeline, one image; 300 and 7: bands.  The
+    same with bf16 activations."""
+    B = 512
+    x = torch.from_numpy(synthetic.make_crops(64, 23)).to(device).repeat(8, 1, 1, 1).contiguous()
+    x += torch.linspace(-0.25, 0.25, B, device=device).view(B, 1, 1, 1)
+    mb = MobileFaceNet(512, act_dtype="bf16")
+    mb.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state_dict_np.items()})
+    mb = mb.to(device).eval()
+    for model in (hip_model, mb):
+        full = model(x).cpu()
+        assert torch.isfinite(full).all()
+        assert torch.equal(model(x[:256].contiguous()).cpu(), full[:256])
+        assert torch.equal(model(x[:300].contiguous()).cpu(), full[:300])
+        for lo in (0, 255, 256, 505):
+            assert torch.equal(model(x[lo:lo + 7].contiguous()).cpu(), full[lo:lo + 7]), lo
+
+
 def test_band_configurations_agree_bit_for_bit(hip_model, device):
     """The block kernels run short bands while those fit the chip in one go (up to 18 or 36 images, depending on
     the layer) and tall bands beyond; conv_3 has two tall heights (7 and 14 rows, whichever needs less time for its
