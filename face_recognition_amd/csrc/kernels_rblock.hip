@@ -115,6 +115,19 @@ template <int N> struct QuadLoad {
     }
 };
 
+// -DRB_STAMPS: per wave, shader-clock cycles per part of the slice loop, summed over the kernel (diagnostic builds only)
+#ifdef RB_STAMPS
+__device__ unsigned long long fra_rb_cycles[65536 * 8 * 8];
+extern "C" int fra_dbg_read(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fra_rb_cycles), bytes, 0, hipMemcpyDeviceToHost);
+}
+#define RB_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define RB_ACC(i, a, b) dbg[i] += (b) - (a)
+#else
+#define RB_T(var)
+#define RB_ACC(i, a, b)
+#endif
+
 template <int C, int CEXP, int H, int TR> constexpr int rblock_lds_bytes() {
     return (TR + 2) * block_pitch<H, 1>() * 144 + 2 * RbPkg<C>::BYTES;
 }
@@ -264,6 +277,10 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
         dw.run(pacc);
     };
 
+#ifdef RB_STAMPS
+    unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    RB_T(t_begin);
+#endif
     // A workgroup keeps its band and walks over images blockIdx.y, blockIdx.y + gridDim.y, ...
     for (int img = blockIdx.y; img < B; img += gridDim.y) {
         const bool has_next = img + (int)gridDim.y < B;
@@ -283,22 +300,31 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
             for (int c = 0; c < NCH; ++c, ++p) {
                 const int buf = c & 1;                         // NCH is even: the parity carries across blocks and images
                 // next package into the other buffer (last read before the previous barrier)
+                RB_T(ts);
 #ifndef RB_ABL_NO_STAGE
                 if (p + 1 < npk) stage(p + 1, buf ^ 1);
                 else if (has_next) stage(0, buf ^ 1);
 #endif
+                RB_T(t0);
+                RB_ACC(5, ts, t0);
 #ifndef RB_ABL_NO_EXPAND
                 expand(buf);
 #endif
+                RB_T(t1);
+                RB_ACC(0, t0, t1);
                 // the image of this slice is complete.  Not __syncthreads(): its fence would also wait for the LDS-DMA in flight
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef RB_ABL_NO_BARRIER1
                 __builtin_amdgcn_s_barrier();
 #endif
                 asm volatile("" ::: "memory");
+                RB_T(t2);
+                RB_ACC(1, t1, t2);
 #ifndef RB_ABL_NO_DW
                 dwproject(buf);
 #endif
+                RB_T(t3);
+                RB_ACC(2, t2, t3);
                 if (c == NCH - 1 && dw_active) {
                     // ---- epilogue in registers: x <- round((acc + x) + b3), channel for channel what the lane holds ----
                     QuadLoad<NT16> bq3;                        // b3 of channels 16 n + 4 g ..
@@ -337,12 +363,22 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                RB_T(t4);
+                RB_ACC(3, t3, t4);
 #ifndef RB_ABL_NO_BARRIER2
                 __syncthreads();                               // image free, next package visible
 #endif
+                RB_T(t5);
+                RB_ACC(4, t4, t5);
             }
         }
     }
+#ifdef RB_STAMPS
+    RB_T(t_end);
+    dbg[7] = t_end - t_begin;
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) fra_rb_cycles[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 + i] = dbg[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
