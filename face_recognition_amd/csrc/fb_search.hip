@@ -490,6 +490,67 @@ __global__ __launch_bounds__(256) void select_topk_kernel(const float* __restric
     }
 }
 
+// One WAVE per query (four queries per block) for up to 64 WSEL candidates -- the partial lists of a search, the shard
+// lists of a merge: a lane keeps its candidates in registers, a round is a lane-local minimum and six shuffle steps,
+// nothing goes through LDS and nothing waits at a barrier.  Same order as select_topk_kernel: ascending
+// (distance, index), round i picks the smallest pair greater than round i - 1's.
+// kth_floor != nullptr: instead of the k results, the score floor of the query (see score_floor below).
+static const int WSEL = 16;
+__global__ __launch_bounds__(256) void select_topk_wave_kernel(const float* __restrict__ dist, const int* __restrict__ idx,
+                                                               int lists, long strideL, long strideQ, int len, int k, int Q,
+                                                               float* __restrict__ dist_out, int* __restrict__ idx_out,
+                                                               const float* __restrict__ qn, float* __restrict__ kth_floor) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;                                    // wave-uniform
+    const int total = lists * len;
+    float cd[WSEL];
+    int ci[WSEL];
+#pragma unroll
+    for (int u = 0; u < WSEL; ++u) {
+        const int c = lane + 64 * u;
+        cd[u] = INFINITY;
+        ci[u] = -1;
+        if (c < total) {
+            const int l = c / len, j = c - l * len;
+            const long a = l * strideL + (long)q * strideQ + j;
+            cd[u] = dist[a];
+            ci[u] = idx[a];
+        }
+    }
+    float last_d = -INFINITY;
+    int last_i = -1;
+    bool found = true;
+    for (int round = 0; round < k; ++round) {
+        float bd = INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < WSEL; ++u) {
+            const float d = cd[u];
+            const int i = ci[u];
+            const bool open = i >= 0 && (round == 0 || pair_less(last_d, last_i, d, i));
+            if (open && pair_less(d, i, bd, bi)) { bd = d; bi = i; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float od = __shfl_xor(bd, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (pair_less(od, oi, bd, bi)) { bd = od; bi = oi; }
+        }
+        found = found && bi != 0x7fffffff;
+        if (!kth_floor && lane == 0) {
+            dist_out[(size_t)q * k + round] = found ? bd : INFINITY;
+            idx_out[(size_t)q * k + round] = found ? bi : -1;
+        }
+        last_d = found ? bd : INFINITY;
+        last_i = found ? bi : 0x7fffffff;                  // nothing is greater than this pair: later rounds find nothing
+    }
+    if (kth_floor && lane == 0) {
+        const float q2 = qn[q];
+        kth_floor[q] = found ? 0.5f * (q2 - last_d) - 4e-7f * (fabsf(q2) + last_d) - 1e-30f : -INFINITY;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // score floor of each query from the partial lists of a pass over PART of the gallery: the k-th smallest
 // distance d_k among them bounds the k-th smallest over the whole gallery from above, so every row of the final
@@ -544,7 +605,10 @@ __global__ __launch_bounds__(256) void threshold_score_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------
 static void launch_select(hipStream_t s, int Q, const float* dist, const int* idx, int lists, long strideL, long strideQ, int len,
                           int index_base, int k, float* dist_out, int* idx_out) {
-    if ((long)lists * len <= 256L * SELECT_CACHE)
+    if (idx && (long)lists * len <= 64L * WSEL)
+        hipLaunchKernelGGL(select_topk_wave_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, dist, idx, lists, strideL, strideQ, len, k, Q,
+                           dist_out, idx_out, (const float*)nullptr, (float*)nullptr);
+    else if ((long)lists * len <= 256L * SELECT_CACHE)
         hipLaunchKernelGGL(select_topk_kernel<SELECT_CACHE>, dim3(Q), dim3(256), 0, s, dist, idx, lists, strideL, strideQ, len,
                            index_base, k, dist_out, idx_out);
     else
@@ -750,7 +814,11 @@ static int search_packed(fb_handle* h, const float* queries, int Q, int k, float
         rc = launch_search_ks<T, 1>(KS, dim3((unsigned)(QT * S1)), lds, s, G, h->negh, qh, qn, pd, pi, nullptr, 0, T1, tps1, QT, S1,
                                     Qpad, (int)h->index_base);
         if (rc) return rc;
-        hipLaunchKernelGGL(score_floor_kernel, dim3((Qpad + 255) / 256), dim3(256), 0, s, pd, pi, qn, P1, Qpad, KS, k, fl);
+        if ((long)P1 * KS <= 64L * WSEL)
+            hipLaunchKernelGGL(select_topk_wave_kernel, dim3((Qpad + 3) / 4), dim3(256), 0, s, pd, pi, P1, (long)Qpad * KS, (long)KS, KS, k,
+                               Qpad, (float*)nullptr, (int*)nullptr, qn, fl);
+        else
+            hipLaunchKernelGGL(score_floor_kernel, dim3((Qpad + 255) / 256), dim3(256), 0, s, pd, pi, qn, P1, Qpad, KS, k, fl);
         FRA_HIP(hipGetLastError());
     }
     const size_t o1 = (size_t)P1 * Qpad * KS;
