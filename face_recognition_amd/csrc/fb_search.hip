@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void select_topk_kernel(const float* __restric
 // lists of a merge: a lane keeps its candidates in registers, a round is a lane-local minimum and six shuffle steps,
 // nothing goes through LDS and nothing waits at a barrier.  Same order as select_topk_kernel: ascending
 // (distance, index), round i picks the smallest pair greater than round i - 1's.
-// kth_floor != nullptr: instead of the k results, the score floor of the query (see score_floor below).
+// kth_floor != nullptr: instead of the k results, the score floor of the query (below).
 static const int WSEL = 16;
 __global__ __launch_bounds__(256) void select_topk_wave_kernel(const float* __restrict__ dist, const int* __restrict__ idx,
                                                                int lists, long strideL, long strideQ, int len, int k, int Q,
@@ -552,39 +552,12 @@ __global__ __launch_bounds__(256) void select_topk_wave_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// score floor of each query from the partial lists of a pass over PART of the gallery: the k-th smallest
-// distance d_k among them bounds the k-th smallest over the whole gallery from above, so every row of the final
-// answer scores at least (|q|^2 - d_k) / 2.  The floor is that score minus a margin for the two roundings
-// between a score and its distance (rows that TIE with the k-th best must still pass the lists' strict
-// comparison).  Fewer than k candidates: no floor.  One thread per query.
+// Score floor of each query from the partial lists of a pass over PART of the gallery (select_topk_wave_kernel with
+// kth_floor): the k-th smallest distance d_k among them bounds the k-th smallest over the whole gallery from above,
+// so every row of the final answer scores at least (|q|^2 - d_k) / 2.  The floor is that score minus a margin for the
+// two roundings between a score and its distance (rows that TIE with the k-th best must still pass the lists' strict
+// comparison).  Fewer than k candidates: no floor.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void score_floor_kernel(const float* __restrict__ pdist, const int* __restrict__ pidx,
-                                                          const float* __restrict__ qn, int lists, int Qpad, int KS, int k,
-                                                          float* __restrict__ qfloor) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= Qpad) return;
-    float best[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) best[j] = INFINITY;       // ascending; best[k - 1] is the k-th smallest so far
-    for (int l = 0; l < lists; ++l)
-        for (int j = 0; j < KS; ++j) {
-            const size_t a = ((size_t)l * Qpad + q) * KS + j;
-            if (pidx[a] < 0) continue;
-            float d = pdist[a];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {                  // insertion by compare-exchange, all in registers
-                const float lo = fminf(best[i], d), hi = fmaxf(best[i], d);
-                best[i] = lo;
-                d = hi;
-            }
-        }
-    float dk = INFINITY;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) if (i == k - 1) dk = best[i];
-    const float q2 = qn[q];
-    qfloor[q] = dk < INFINITY ? 0.5f * (q2 - dk) - 4e-7f * (fabsf(q2) + dk) - 1e-30f : -INFINITY;
-}
-
 __global__ __launch_bounds__(256) void threshold_score_kernel(const float* __restrict__ minimum,
                                                               long long* __restrict__ idx,
                                                               float* __restrict__ score, int Q, float limit) {
@@ -814,11 +787,9 @@ static int search_packed(fb_handle* h, const float* queries, int Q, int k, float
         rc = launch_search_ks<T, 1>(KS, dim3((unsigned)(QT * S1)), lds, s, G, h->negh, qh, qn, pd, pi, nullptr, 0, T1, tps1, QT, S1,
                                     Qpad, (int)h->index_base);
         if (rc) return rc;
-        if ((long)P1 * KS <= 64L * WSEL)
-            hipLaunchKernelGGL(select_topk_wave_kernel, dim3((Qpad + 3) / 4), dim3(256), 0, s, pd, pi, P1, (long)Qpad * KS, (long)KS, KS, k,
-                               Qpad, (float*)nullptr, (int*)nullptr, qn, fl);
-        else
-            hipLaunchKernelGGL(score_floor_kernel, dim3((Qpad + 255) / 256), dim3(256), 0, s, pd, pi, qn, P1, Qpad, KS, k, fl);
+        static_assert(4 * 8 * 8 <= 64 * WSEL, "the first pass's lists (at most 8 splits x 4, 8 entries each) fit one wave");
+        hipLaunchKernelGGL(select_topk_wave_kernel, dim3((Qpad + 3) / 4), dim3(256), 0, s, pd, pi, P1, (long)Qpad * KS, (long)KS, KS, k,
+                           Qpad, (float*)nullptr, (int*)nullptr, qn, fl);
         FRA_HIP(hipGetLastError());
     }
     const size_t o1 = (size_t)P1 * Qpad * KS;
