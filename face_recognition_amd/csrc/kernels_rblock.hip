@@ -128,8 +128,15 @@ extern "C" int fra_dbg_read(void* dst, size_t bytes) {
 #define RB_ACC(i, a, b)
 #endif
 
+#ifndef RB_FLAGS
+#define RB_FLAGS 1         // whole-image workgroups synchronise wave to wave through flags in LDS instead of barriers
+#endif
+#ifndef RB_SPIN_LIMIT
+#define RB_SPIN_LIMIT (1 << 20)   // polls (some 0.1 s) after which a wait gives up: wrong results instead of a wave that never ends
+#endif
+// whole-image workgroups keep TWO activation images (slices alternate) and a block of flag words
 template <int C, int CEXP, int H, int TR> constexpr int rblock_lds_bytes() {
-    return (TR + 2) * block_pitch<H, 1>() * 144 + 2 * RbPkg<C>::BYTES;
+    return ((TR == H && RB_FLAGS) ? 2 : 1) * (TR + 2) * block_pitch<H, 1>() * 144 + 2 * RbPkg<C>::BYTES + ((TR == H && RB_FLAGS) ? 128 : 0);
 }
 
 template <typename T, int C, int CEXP, int H, int TR, int NW>
@@ -149,7 +156,14 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     constexpr int KS = C / 32, NT16 = C / 16, NCH = CEXP / 64;
     constexpr int PITCH = block_pitch<H, 1>(), SLOT = 144;
     constexpr int ES_BYTES = RIN * PITCH * SLOT;
-    constexpr int LDS_BYTES = ES_BYTES + 2 * PK::BYTES;
+    // FL: no workgroup-wide barriers in the slice loop.  A wave's expand stage writes its tile's rows, its depthwise
+    // stage reads those and the two neighbouring tiles' rows: it waits for those two waves only (flags in LDS), and
+    // with two activation images (slice parity) a wave may expand the next slice while its neighbours still read this
+    // one.  The tile-less last wave copies the weight packages and tells the others when one has landed.
+    constexpr bool FL = WHOLE && RB_FLAGS;
+    constexpr int NIMG = FL ? 2 : 1;
+    constexpr int OFF_PKG = NIMG * ES_BYTES, OFF_FLAGS = OFF_PKG + 2 * PK::BYTES;
+    constexpr int LDS_BYTES = OFF_FLAGS + (FL ? 128 : 0);
     constexpr int MTIW = (MTI + NW - 1) / NW;              // input tiles per wave
     // with at most NW / 2 input tiles two waves share one and expand two of the slice's four channel tiles each
     constexpr bool ESPLIT = MTI <= NW / 2;
@@ -173,7 +187,7 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     // ---- package staging: piece k (1 KB) is copied by wave k % NW ----------------------------------------------
     auto stage = [&](int p, int buf) {
         const char* g = WP + (size_t)p * PK::BYTES + lane * 16;
-        char* l = lds + ES_BYTES + buf * PK::BYTES;
+        char* l = lds + OFF_PKG + buf * PK::BYTES;
 #pragma unroll
         for (int j = 0; j < (PK::PIECES + NW - 1) / NW; ++j) {
             const int k = wave + NW * j;
@@ -181,13 +195,18 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
                 __builtin_amdgcn_global_load_lds((GPTR)(g + k * 1024), (LPTR)(l + k * 1024), 16, 0, 0);
         }
     };
-    stage(0, 0);
+    if constexpr (!FL) stage(0, 0);
 #ifdef RB_PRIO_YOUNG
     if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses issue arbitration otherwise
 #endif
 
     // the activation image starts as zeros: border slots and out-of-image rows are never written afterwards
-    for (int i = tid; i < ES_BYTES / 16; i += NW * 64) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < NIMG * ES_BYTES / 16; i += NW * 64) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // flags (FL): exp_done[w] / dw_done[w] = slices wave w has expanded / finished reading, pkg_ready = packages landed
+    volatile int* exp_done = reinterpret_cast<volatile int*>(lds + OFF_FLAGS);
+    volatile int* dw_done = exp_done + 8;
+    volatile int* pkg_ready = exp_done + 16;
+    if (FL && tid < 32) exp_done[tid] = 0;
 
     // ---- this lane's pixels: tile ti, subtile st -> LDS slot and offset inside an image -------------------------
     const int we = ESPLIT ? (wave & (MTIP - 1)) : wave, en = ESPLIT ? wave / MTIP : 0;   // wave-uniform
@@ -248,27 +267,27 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     }
     f32x4 pacc[NSUB][NT16];  // tile n of subtile st, register i <-> output channel 16 n + 4 g + i
 
-    auto expand = [&](int buf) {
+    auto expand = [&](int buf, int ioff) {                 // ioff: byte offset of the activation image to write
         if (we >= MTI || en >= 2) return;                  // wave-uniform
-        const int base = ES_BYTES + buf * PK::BYTES;
+        const int base = OFF_PKG + buf * PK::BYTES;
         const int w1l = base + (16 * (g4 & 1) + m16) * PK::PW1 + 16 * (g4 >> 1);
         const int pl = base + PK::OFF_B1 + 16 * g4;
 #pragma unroll
         for (int tt = 0; tt < MTIW; ++tt) {
             if (we + NW * tt >= MTI) break;                // wave-uniform
             if constexpr (ESPLIT) {
-                if (en == 0) { Exp16<T, KS, PK::PW1, 0, 2> ex; ex.w1l = w1l; ex.pl = pl; ex.preamble(); ex.run(xf[tt], lds, lds_px[tt]); }
-                else         { Exp16<T, KS, PK::PW1, 2, 2> ex; ex.w1l = w1l; ex.pl = pl; ex.preamble(); ex.run(xf[tt], lds, lds_px[tt]); }
+                if (en == 0) { Exp16<T, KS, PK::PW1, 0, 2> ex; ex.w1l = w1l; ex.pl = pl; ex.preamble(); ex.run(xf[tt], lds + ioff, lds_px[tt]); }
+                else         { Exp16<T, KS, PK::PW1, 2, 2> ex; ex.w1l = w1l; ex.pl = pl; ex.preamble(); ex.run(xf[tt], lds + ioff, lds_px[tt]); }
             } else {
-                Exp16<T, KS, PK::PW1, 0, 4> ex; ex.w1l = w1l; ex.pl = pl; ex.preamble(); ex.run(xf[tt], lds, lds_px[tt]);
+                Exp16<T, KS, PK::PW1, 0, 4> ex; ex.w1l = w1l; ex.pl = pl; ex.preamble(); ex.run(xf[tt], lds + ioff, lds_px[tt]);
             }
         }
     };
-    auto dwproject = [&](int buf) {
+    auto dwproject = [&](int buf, int ioff) {
         if (!dw_active) return;                            // wave-uniform
-        const int base = ES_BYTES + buf * PK::BYTES;
+        const int base = OFF_PKG + buf * PK::BYTES;
         DwStage<T, 64, NT16, PK::PW3, ST1, PITCH * SLOT, 4, NSUB> dw;
-        dw.tb = tb;
+        dw.tb = tb + ioff;
         dw.set_lane(m16, g4);
         dw.w2l = base + PK::OFF_W2 + (g4 & 1) * dw_wplane(64) + m16 * 4;
         dw.pb = base + PK::OFF_B2 + 16 * g4;
@@ -281,6 +300,118 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     RB_T(t_begin);
 #endif
+    // ---- epilogue of a block in registers: x <- round((acc + x) + b3), channel for channel what the lane holds; the last
+    // block of a launch also stores the image ----
+    auto block_epilogue = [&](int buf, bool store, int img) {
+        QuadLoad<NT16> bq3;                                // b3 of channels 16 n + 4 g ..
+        bq3.issue(OFF_PKG + buf * PK::BYTES + PK::OFF_B3 + 16 * g4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bq3.pin();
+        // subtile st of the tile, accumulated in pacc[a]
+        auto finish = [&](auto st_c, auto a_c) {
+            constexpr int st = decltype(st_c)::value, a = decltype(a_c)::value;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = 2 * ks + (j >> 2), i = j & 3;
+                    const float v = pacc[a][n][i] + (float)xf[0][st][ks][j];
+                    xf[0][st][ks][j] = (T)(v + bq3.q[n][i]);
+                }
+            if (store && lds_px[0][st] >= 0) {
+                T* Oimg = O + (size_t)img * H * W * C;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const V8 v = xf[0][st][ks];
+                    *reinterpret_cast<V4*>(Oimg + x_off[0][st] + 32 * ks) = V4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<V4*>(Oimg + x_off[0][st] + 32 * ks + 16) = V4{v[4], v[5], v[6], v[7]};
+                }
+            }
+        };
+        typedef std::integral_constant<int, 0> I0;
+        typedef std::integral_constant<int, 1> I1;
+        if constexpr (SSPLIT) {
+            if (en == 0) finish(I0{}, I0{});               // wave-uniform
+            else finish(I1{}, I0{});
+        } else {
+            finish(I0{}, I0{});
+            finish(I1{}, std::integral_constant<int, NSUB - 1>{});
+        }
+    };
+
+    if constexpr (FL) {
+        // ================= whole-image workgroups: wave-to-wave flags, no barrier in the slice loop =================
+        // Slices are numbered through (s = 0, 1, ... over images, blocks and slices); slice s uses activation image and
+        // package buffer s & 1.
+        static_assert(MTIW == 1 && !ESPLIT && MTI == MTO && MTO < NW, "one tile per wave and a wave to spare");
+        __syncthreads();                                   // zeroed images and flags
+        const int nimg = (B - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
+        const int NS = nimg * npk;
+        // spin until `cond` holds for every lane (flags only ever grow)
+        auto wait_flags = [&](auto cond) {
+            for (int spin = 0; spin < RB_SPIN_LIMIT; ++spin) {
+                if (__builtin_amdgcn_ballot_w64(!cond()) == 0) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+        };
+        if (wave == NW - 1) {
+            // ---- loader: package s goes into buffer s & 1 once every wave has finished reading slice s - 2 ----
+            // (loading the half the expand stage reads as soon as every wave has expanded slice s - 2, with a flag of
+            // its own, was measured: no faster)
+            for (int s = 0; s < NS; ++s) {
+                if (s >= 2) wait_flags([&] { return lane >= MTO || dw_done[lane & 7] >= s - 1; });
+                const char* g = WP + (size_t)(s % npk) * PK::BYTES + lane * 16;
+                char* l = lds + OFF_PKG + (s & 1) * PK::BYTES;
+#pragma unroll
+                for (int k = 0; k < PK::PIECES; ++k)
+                    __builtin_amdgcn_global_load_lds((GPTR)(g + k * 1024), (LPTR)(l + k * 1024), 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) *pkg_ready = s + 1;
+            }
+        } else if (wave < MTO) {
+            // neighbours whose rows this wave's depthwise window touches (and who read this wave's rows)
+            const int nb = (lane & 1) ? wave + 1 : wave - 1;
+            const bool has_nb = nb >= 0 && nb < MTO;
+            const int nbc = has_nb ? nb : wave;
+            int s = 0;
+            for (int img = blockIdx.y; img < B; img += gridDim.y) {
+                load_x(img);
+#pragma unroll 1
+                for (int b = 0; b < nblk; ++b) {
+#pragma unroll
+                    for (int st = 0; st < NSUB; ++st)
+#pragma unroll
+                        for (int n = 0; n < NT16; ++n) pacc[st][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                    for (int c = 0; c < NCH; ++c, ++s) {
+                        const int buf = s & 1, ioff = buf * ES_BYTES;
+                        RB_T(t0);
+                        // package s has landed; the neighbours have finished reading this image's previous contents (slice s - 2)
+                        wait_flags([&] { return *pkg_ready >= s + 1 && (!has_nb || dw_done[nbc] >= s - 1); });
+                        RB_T(t1);
+                        RB_ACC(1, t0, t1);
+                        expand(buf, ioff);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the rows are in LDS before the flag goes up
+                        if (lane == 0) exp_done[wave] = s + 1;
+                        RB_T(t2);
+                        RB_ACC(0, t1, t2);
+                        wait_flags([&] { return !has_nb || exp_done[nbc] >= s + 1; });
+                        RB_T(t3);
+                        RB_ACC(3, t2, t3);
+                        dwproject(buf, ioff);
+                        RB_T(t4);
+                        RB_ACC(2, t3, t4);
+                        if (c == NCH - 1) block_epilogue(buf, b == nblk - 1, img);   // reads b3 from the package
+                        asm volatile("" ::: "memory");
+                        if (lane == 0) dw_done[wave] = s + 1;                  // every read of image and package has returned
+                        RB_T(t5);
+                        RB_ACC(4, t4, t5);
+                    }
+                }
+            }
+        }
+    } else {
     // A workgroup keeps its band and walks over images blockIdx.y, blockIdx.y + gridDim.y, ...
     for (int img = blockIdx.y; img < B; img += gridDim.y) {
         const bool has_next = img + (int)gridDim.y < B;
@@ -308,7 +439,7 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
                 RB_T(t0);
                 RB_ACC(5, ts, t0);
 #ifndef RB_ABL_NO_EXPAND
-                expand(buf);
+                expand(buf, 0);
 #endif
                 RB_T(t1);
                 RB_ACC(0, t0, t1);
@@ -321,47 +452,11 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
                 RB_T(t2);
                 RB_ACC(1, t1, t2);
 #ifndef RB_ABL_NO_DW
-                dwproject(buf);
+                dwproject(buf, 0);
 #endif
                 RB_T(t3);
                 RB_ACC(2, t2, t3);
-                if (c == NCH - 1 && dw_active) {
-                    // ---- epilogue in registers: x <- round((acc + x) + b3), channel for channel what the lane holds ----
-                    QuadLoad<NT16> bq3;                        // b3 of channels 16 n + 4 g ..
-                    bq3.issue(ES_BYTES + buf * PK::BYTES + PK::OFF_B3 + 16 * g4);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    bq3.pin();
-                    // subtile st of the tile, accumulated in pacc[a]
-                    auto finish = [&](auto st_c, auto a_c) {
-                        constexpr int st = decltype(st_c)::value, a = decltype(a_c)::value;
-#pragma unroll
-                        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const int n = 2 * ks + (j >> 2), i = j & 3;
-                                const float v = pacc[a][n][i] + (float)xf[0][st][ks][j];
-                                xf[0][st][ks][j] = (T)(v + bq3.q[n][i]);
-                            }
-                        if (b == nblk - 1 && lds_px[0][st] >= 0) {
-                            T* Oimg = O + (size_t)img * H * W * C;
-#pragma unroll
-                            for (int ks = 0; ks < KS; ++ks) {
-                                const V8 v = xf[0][st][ks];
-                                *reinterpret_cast<V4*>(Oimg + x_off[0][st] + 32 * ks) = V4{v[0], v[1], v[2], v[3]};
-                                *reinterpret_cast<V4*>(Oimg + x_off[0][st] + 32 * ks + 16) = V4{v[4], v[5], v[6], v[7]};
-                            }
-                        }
-                    };
-                    typedef std::integral_constant<int, 0> I0;
-                    typedef std::integral_constant<int, 1> I1;
-                    if constexpr (SSPLIT) {
-                        if (en == 0) finish(I0{}, I0{});       // wave-uniform
-                        else finish(I1{}, I0{});
-                    } else {
-                        finish(I0{}, I0{});
-                        finish(I1{}, std::integral_constant<int, NSUB - 1>{});
-                    }
-                }
+                if (c == NCH - 1 && dw_active) block_epilogue(buf, b == nblk - 1, img);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 RB_T(t4);
                 RB_ACC(3, t3, t4);
@@ -372,6 +467,7 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
                 RB_ACC(4, t4, t5);
             }
         }
+    }
     }
 #ifdef RB_STAMPS
     RB_T(t_end);

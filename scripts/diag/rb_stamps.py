@@ -22,7 +22,9 @@ buf = np.zeros((nwg, 8, 8), dtype=np.uint64)
 assert lib.fra_dbg_read(buf.ctypes.data, buf.nbytes) == 0
 c = buf.astype(np.float64)
 print("median cycles per wave over %d workgroups (kernel total %.0f)" % (nwg, np.median(c[:, :, 7])))
-parts = ("expand", "wait + barrier after expand", "depthwise + project (+ epilogue)", "block epilogue + wait for the next package", "barrier after the slice", "package request")
+# chained launch (flags): what each counter holds; the per-block launches with barriers count
+# expand | barrier after expand | depthwise + project | block epilogue + package wait | barrier after the slice | package request
+parts = ("expand + flag", "wait: package, neighbours done with slice s - 2", "depthwise + project", "wait: neighbours' rows", "block epilogue + flag", "-")
 for w in range(8):
     m = np.median(c[:, w, :], axis=0)
     print("  wave %d: %s" % (w, ", ".join("%s %.0f" % (p, v) for p, v in zip(parts, m[:6]))), " total %.0f" % m[7])
