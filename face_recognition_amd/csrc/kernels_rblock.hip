@@ -540,11 +540,12 @@ static int launch_rblock_t(int c, int cexp, int h, const void* x, const void* wp
 }
 
 bool rblock_chain_pays(int c, int cexp, int h, int B) {
-    // whole-image workgroups: worth it once they fill more of the chip than two-band workgroups would
+    // one launch of whole-image workgroups takes about as long for one image as for a chip full of them; it wins over
+    // per-block launches as soon as the two-row bands of a batch no longer fit the chip in one go
     // (FRA_RB_CHAIN_MIN=<batch> moves the limit, for measurements)
     static const int min_b = [] { const char* e = getenv("FRA_RB_CHAIN_MIN"); return e ? atoi(e) : 0; }();
     if (min_b > 0) return c == 128 && cexp == 256 && h == 14 && B >= min_b;
-    return c == 128 && cexp == 256 && h == 14 && (int64_t)B * 2 > rb_compute_units();
+    return c == 128 && cexp == 256 && h == 14 && (int64_t)B * 7 > rb_compute_units();
 }
 
 int launch_rblock(int dt, int c, int cexp, int h, const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s) {

@@ -116,11 +116,13 @@ def test_chained_and_per_block_launches_agree_bit_for_bit(hip_model, device):
     hip_model.set_chain(False)
     try:
         assert hip_model.launch_plan(150) == list(range(len(names)))
-        assert torch.equal(hip_model(x).cpu(), want)
+        assert torch.equal(hip_model(x).cpu(), want)                                 # whole images, one block per launch
+        assert torch.equal(hip_model(x[:60].contiguous()).cpu(), want[:60])          # 7-row bands
     finally:
         hip_model.set_chain(True)
-    assert torch.equal(hip_model(x[:8].contiguous()).cpu(), want[:8])  # 2-row bands
-    assert torch.equal(hip_model(x[:60].contiguous()).cpu(), want[:60])  # 7-row bands
+    assert torch.equal(hip_model(x[:8].contiguous()).cpu(), want[:8])                # 2-row bands
+    assert hip_model.launch_plan(60)[first:first + 6] == [first] * 6
+    assert torch.equal(hip_model(x[:60].contiguous()).cpu(), want[:60])              # one launch on a part-filled chip
 
 
 def test_row_pipeline_kernel_matches_band_kernels(device, hip_model, state_dict_np):
