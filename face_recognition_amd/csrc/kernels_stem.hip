@@ -18,301 +18,434 @@
 // 16-channel group are 8 CONSECUTIVE channels and travel as one 16-byte unit.  Slope arrays hold
 // (PReLU slope - 1).
 //
-// LDS image: 64 pixel slots of 128 bytes per row; unit u (8 channels) of slot s sits at u ^ (s & 7).
-// The stem stage writes it from the MFMA layout (lane = pixel, two units per lane), which the XOR
-// keeps conflict free; the depthwise stage reads it with lane = (pixel = lane >> 3, unit = lane & 7),
-// so eight lanes cover one whole slot, a wave's store is 1 KB of contiguous NHWC output, and a lane
-// works on the same 8 channels for the whole kernel: its 3x3 weights, bias and slopes live in
-// registers.  With 64 slots per row the XOR key of a tap does not depend on the row, so the nine
-// tap addresses are three lane registers plus immediates.  The reads run three taps ahead of the
-// FMAs through a register ring with counted waits (LDS returns data in order).
+// LDS image: rows of SD_ROWB bytes, pixel slots of 128 bytes (slot = x + 1; slots 0 and 57 are the zero border); unit u
+// (8 channels) of slot s sits at u ^ (s & 7).  The stem stage writes it from the MFMA layout (lane = pixel, two units
+// per lane), which the XOR keeps conflict free.
+//
+// The depthwise stage runs on the SPARSE 16x16x64 MFMA like the fused blocks' (block_stages.h has the operand maps):
+// D[ch][px] = sum over (tap slot, ch') Diag[ch][(slot, ch')] . E[(slot, ch')][px], one instruction per window row
+// (tap slots 0..2 = taps (p, 0..2), slot 3 has weight zero), for 16 channels and 16 pixels.  Wave w owns columns
+// 8 w .. 8 w + 7 of the band's four rows as two tiles of 2 rows x 8 columns: tile t = rows t and t + 2.  A B lane
+// (pixel m, tap slot g) reads the two units of a 16-channel chunk of ITS tap column for image rows a + 2 (m >> 3):
+// that operand ("set a") is window row a of tile 0 AND window row a - 1 of tile 1, so the four sets of a chunk feed
+// six MFMAs -- 32 LDS reads per lane and band where one lane per (pixel, unit) needs 36.  The XOR key depends on the
+// column only, so every tap address is one of eight lane registers plus an immediate; a row pitch of 58.5 slots puts
+// rows two apart into opposite halves of the LDS banks and the 16 pixels of a set read 16 different bank groups.
+// The diagonal operands of the 12 (window row, chunk) pairs are built once per workgroup and kept in LDS as ready
+// fragments (16 bytes per lane); the accumulators start from the bias.  The reads run SD_PD sets ahead of the MFMAs through a register ring with
+// counted waits (LDS returns data in order).  A lane ends up with channels 16 c + 4 g .. + 3 of its pixel; one
+// v_permlane16_swap per register between the results of chunks 2 h and 2 h + 1 leaves every lane with one whole
+// unit (16 bytes) and the four lanes of a pixel with 64 contiguous bytes of the NHWC output per store instruction.
 #include "common.h"
 
 namespace fra {
 
 #define STEM_LDS_READ16(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
-constexpr int SD_PITCH = 64;                 // pixel slots per image row in LDS
-constexpr int SD_PD = 3, SD_RING = SD_PD + 1;
+constexpr int SD_ROWB = 58 * 128 + 64;       // bytes per image row in LDS
+#ifndef SD_PD_SETS
+#define SD_PD_SETS 2
+#endif
+constexpr int SD_PD = SD_PD_SETS, SD_RING = SD_PD + 1;   // sets of LDS reads in flight ahead of the MFMAs
 
-// depthwise stage of one wave: TR output rows x 8 pixels x 64 channels, 9 taps per row
-template <typename T, int TR> struct StemDwStage {
+// depthwise stage of one wave: 4 output rows x 8 columns x 64 channels
+template <typename T> struct StemDwStage {
+    typedef typename vec4<T>::type V4;
     typedef typename vec8<T>::type V8;
-    static constexpr int STEPS = 9 * TR;
-    V8 er[SD_RING];
-    V8 wk[9];
-    f32x4 b2a, b2b, s2a, s2b;
-    float d[8];
-    int eb[3];          // LDS address of this lane's unit in the slots of column x + kx, row 0
-    T* out;             // this lane's output address in row 0 of the band
+    typedef typename vec16<T>::type V16;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    static constexpr int SETS = 16;       // (chunk c, set a): step 4 c + a
+    V8 er[SD_RING][2];
+    V8 dg[SD_RING + 1];                   // the diagonal of (window row a, chunk c) arrives with set (c, a); tile 1 uses it one set later
+    int idx;                              // positions of the sparse fragment's elements
+    f32x4 bias[4], slope[4];              // channels 16 c + 4 g .. + 3; slope holds slope - 1
+    f32x4 acc[2];
+    int dga;                              // LDS address of this lane's diagonal fragment (0, 0); + ((4 p + c) * 64) * 16
+    u32x2 held[2];                        // the even chunk's rounded results, per tile
+    int ta[8];                            // LDS address of unit u of this lane's tap column, set 0
+    T* out;                               // this lane's 16 output bytes of tile 0, chunk pair 0
 
-    template <int ST> __device__ __forceinline__ void issue() {
-        constexpr int row = ST / 9, tap = ST % 9, ky = tap / 3, kx = tap % 3;
-        STEM_LDS_READ16(er[ST % SD_RING], eb[kx], (row + ky) * SD_PITCH * 128);
+    // m = lane & 15, g = lane >> 4; the same fragment maps as DwStage::set_lane
+    static __device__ __forceinline__ void lane_masks(int m, int g, uint32_t (&msk)[4], int& idx) {
+        const bool mine = (m >> 3) == (g >> 1);
+        const int r = (m & 7) >> 2, pos = m & 3, other = pos ^ 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) msk[i] = !mine ? 0u : (i == r ? 0x0000FFFFu : (i == 2 + r ? 0xFFFF0000u : 0u));
+        idx = 0x4444;
+        idx = (idx & ~(0xF << (4 * r))) | ((pos | (other << 2)) << (4 * r));
+        idx = (idx & ~(0xF << (4 * (2 + r)))) | ((other | (pos << 2)) << (4 * (2 + r)));
     }
-    template <int ST = 0> __device__ __forceinline__ void preamble() {
-        if constexpr (ST < SD_PD) { issue<ST>(); preamble<ST + 1>(); }
+    // one lane's diagonal fragment of (window row p, chunk c) from the [9][64] depthwise weights: row m of the
+    // chunk, tap slots 2 (g & 1) and 2 (g & 1) + 1 of unit g >> 1 (slot 3 has weight zero)
+    static __device__ __forceinline__ u32x4 fragment(const unsigned short* w2, int p, int c, int m, int g) {
+        uint32_t msk[4];
+        int idx_unused;
+        lane_masks(m, g, msk, idx_unused);
+        const uint32_t even = w2[(3 * p + 2 * (g & 1)) * 64 + 16 * c + m];
+        const uint32_t odd = w2[(3 * p + 1) * 64 + 16 * c + m];
+        const uint32_t w = even | ((g & 1) ? 0u : odd << 16);
+        return u32x4{w & msk[0], w & msk[1], w & msk[2], w & msk[3]};
     }
-    template <int ST = 0> __device__ __forceinline__ void run() {
-        if constexpr (ST < STEPS) {
-            constexpr int row = ST / 9, tap = ST % 9, slot = ST % SD_RING;
-            if constexpr (ST + SD_PD < STEPS) issue<ST + SD_PD>();
-            // reads issued after this step's: the next min(PD, steps left) taps
-            constexpr int ahead = (ST + SD_PD < STEPS ? SD_PD : STEPS - 1 - ST);
-            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(er[slot]) : "n"(ahead));
-            if constexpr (tap == 0) {
+    static constexpr int reads_of(int S) { return S % 4 < 3 ? 3 : 2; }
+    static constexpr int reads_after(int S) {        // LDS reads issued after set S's when the wave waits for it
+        int n = 0;
+        for (int k = S + 1; k <= S + SD_PD && k < SETS; ++k) n += reads_of(k);
+        return n;
+    }
+    template <int S> __device__ __forceinline__ void issue() {
+        constexpr int c = S / 4, a = S % 4;
+        STEM_LDS_READ16(er[S % SD_RING][0], ta[2 * c], a * SD_ROWB);
+        STEM_LDS_READ16(er[S % SD_RING][1], ta[2 * c + 1], a * SD_ROWB);
+        if constexpr (a < 3) STEM_LDS_READ16(dg[S % (SD_RING + 1)], dga, ((4 * a + c) * 64) * 16);
+    }
+    template <int S = 0> __device__ __forceinline__ void preamble() {
+        if constexpr (S < SD_PD) { issue<S>(); preamble<S + 1>(); }
+    }
+    // PReLU + rounding of a finished tile; odd chunks pair up with the even chunk before them and store
+    template <int C, int TILE> __device__ __forceinline__ void finish() {
+        V4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    d[j] = fmaf((float)er[slot][j], (float)wk[0][j], b2a[j]);
-                    d[4 + j] = fmaf((float)er[slot][4 + j], (float)wk[0][4 + j], b2b[j]);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) d[j] = fmaf((float)er[slot][j], (float)wk[tap][j], d[j]);
-            }
-            if constexpr (tap == 8) {
-                V8 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o[j] = (T)fmaf(neg_part(d[j]), s2a[j], d[j]);                  // PReLU: s2 = slope - 1
-                    o[4 + j] = (T)fmaf(neg_part(d[4 + j]), s2b[j], d[4 + j]);
-                }
-                *reinterpret_cast<V8*>(out + (size_t)row * 56 * 64) = o;
+        for (int i = 0; i < 4; ++i) o[i] = (T)fmaf(neg_part(acc[TILE][i]), slope[C][i], acc[TILE][i]);
+        const u32x2 w = __builtin_bit_cast(u32x2, o);
+        if constexpr (C % 2 == 0) {
+            held[TILE] = w;
+        } else {
+            // rows (16 lanes) g = 0, 2 keep the even chunk's values and fetch their right neighbour's (the next four
+            // channels); rows g = 1, 3 fetch the odd chunk's values of their left neighbour and keep their own
+            const u32x2 s0 = __builtin_amdgcn_permlane16_swap(held[TILE][0], w[0], false, false);
+            const u32x2 s1 = __builtin_amdgcn_permlane16_swap(held[TILE][1], w[1], false, false);
+            const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+#ifdef STEM_ABL_NOSTORE
+            if (acc[TILE][0] == 12345.678f)
+#endif
+            *reinterpret_cast<u32x4*>(out + (size_t)TILE * 56 * 64 + 32 * (C / 2)) = v;
+        }
+    }
+    template <int S = 0> __device__ __forceinline__ void run() {
+        if constexpr (S < SETS) {
+            constexpr int c = S / 4, a = S % 4, slot = S % SD_RING, ds = S % (SD_RING + 1), dp = (S + SD_RING) % (SD_RING + 1);
+            if constexpr (S + SD_PD < SETS) issue<S + SD_PD>();
+            if constexpr (a < 3)
+                asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(er[slot][0]), "+v"(er[slot][1]), "+v"(dg[ds]) : "n"(reads_after(S)));
+            else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(er[slot][0]), "+v"(er[slot][1]) : "n"(reads_after(S)));
+            const V16 e = __builtin_shufflevector(er[slot][0], er[slot][1], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+            if constexpr (a == 0) acc[0] = bias[c];
+            if constexpr (a == 1) acc[1] = bias[c];
+            if constexpr (a <= 2) acc[0] = smfma16(dg[ds], e, acc[0], idx);
+            if constexpr (a >= 1) acc[1] = smfma16(dg[dp], e, acc[1], idx);     // window row a - 1: the previous set's diagonal
+            if constexpr (a == 3) {
+                finish<c, 0>();
+                finish<c, 1>();
             }
             __builtin_amdgcn_sched_barrier(0);
-            run<ST + 1>();
+            run<S + 1>();
         }
     }
 };
 
 template <typename T, bool U8, int TR, int NW, int MINW>
 __global__ __launch_bounds__(NW * 64, MINW)
-void stemdw_kernel(const void* __restrict__ Xv, int n_src, const T* __restrict__ WA, const float* __restrict__ b1,
-                   const float* __restrict__ s1, const T* __restrict__ W2, const float* __restrict__ b2,
-                   const float* __restrict__ s2, T* __restrict__ O) {
+void stemdw_kernel(const void* __restrict__ Xv, int n_src, int n_items, const T* __restrict__ WA,
+                   const float* __restrict__ b1, const float* __restrict__ s1, const T* __restrict__ W2,
+                   const float* __restrict__ b2, const float* __restrict__ s2, T* __restrict__ O) {
     typedef typename vec8<T>::type V8;
     typedef typename vec4<T>::type V4;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
     constexpr int NT = NW * 64;
-    constexpr int H = 56, W = 56, HI = 112;
-    constexpr int RIN = TR + 2, PITCH = SD_PITCH;
+    constexpr int H = 56, W = 56, HI = 112, NB = H / TR;
+    constexpr int RIN = TR + 2;
     constexpr int PIN = RIN * W;
     constexpr int MTI = (PIN + 31) / 32;
     constexpr int MTIW = (MTI + NW - 1) / NW;
-    static_assert(W % 8 == 0 && W / 8 <= NW && PITCH >= W + 2, "depthwise stage: one wave per 8-pixel column group");
-    constexpr int ES_BYTES = RIN * PITCH * 128;
+    static_assert(W % 8 == 0 && W / 8 <= NW && SD_ROWB >= (W + 2) * 128 && TR == 4, "depthwise stage: one wave per 8-pixel column group, two tiles of two rows");
+    constexpr int ES_BYTES = RIN * SD_ROWB;
     // staged input: 4 planes (3 channels + one all-zero plane for the 5 padding taps) of NR rows x PW columns;
     // input column x sits at column x + 4, so groups of 4 columns line up with 16-byte source loads
     constexpr int NR = 2 * TR + 5, PW = 120, NG = PW / 4;
     constexpr int OFF_IN = ES_BYTES, IN_BYTES = 4 * NR * PW * 2;
     constexpr int OFF_W2 = OFF_IN + IN_BYTES, OFF_B1 = OFF_W2 + 9 * 64 * 2, OFF_S1 = OFF_B1 + 256, OFF_B2 = OFF_S1 + 256,
-                  OFF_S2 = OFF_B2 + 256;
+                  OFF_S2 = OFF_B2 + 256, OFF_WA = OFF_S2 + 256, OFF_DG = OFF_WA + 64 * 32 * 2,
+                  OFF_TOFF = OFF_DG + 12 * 64 * 16;
     static_assert(H % TR == 0, "band height");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const es = lds;
     T* const inp = reinterpret_cast<T*>(lds + OFF_IN);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int band = blockIdx.x, img = blockIdx.y;
-    const int src = img >= n_src ? img - n_src : img;
-    const bool flip = img >= n_src;
-    const int y0 = band * TR, row0 = y0 - 1;
-    const int rin0 = 2 * row0 - 1;                 // input row held by LDS input row 0
 
-    // ---- prologue.  Every global load of the prologue is issued before the first use of any of them, so the
-    // workgroup pays one memory latency, not one per loop; the LDS zeroing runs while they are in flight.
+    // A workgroup walks over items (image, band of TR output rows): item, item + gridDim.x, ...  The input rows of
+    // the NEXT item are requested into registers before this item's stem stage and written to the LDS planes right
+    // after it (the planes are free then, and the depthwise stage needs the registers), so a workgroup waits a
+    // whole memory latency once, at its first item.
     // Input band: column group g holds input columns 4(g-1) .. 4(g-1)+3 (g = 0 and g = NG-1 are padding).
-    // staging items: 4 pixels of one row (x 3 channels for U8).  Half a wave (32 lanes, 30 used) takes one row of
+    // staging pieces: 4 pixels of one row (x 3 channels for U8).  Half a wave (32 lanes, 30 used) takes one row of
     // column groups, NT / 32 rows per pass: shifts and masks instead of divisions by 30 and 13
     constexpr int NROWS = U8 ? NR : 3 * NR, ROWS_PER_PASS = NT / 32;
     constexpr int IN_IT = (NROWS + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
     static_assert(NG <= 32, "staging map: one row of column groups per half wave");
     f32x4 vin[U8 ? 1 : IN_IT];
     unsigned win[U8 ? IN_IT : 1][3];
-    bool in_ok[IN_IT];
-#pragma unroll
-    for (int it = 0; it < IN_IT; ++it) {
-        const int g = tid & 31, cr = (tid >> 5) + ROWS_PER_PASS * it;   // cr = c * NR + ry (fp32) or ry (uint8)
+    // (sg, scr: this thread's column group and first row; rebuilt from an opaque copy of the thread index wherever
+    // they are used, so that nothing derived from them stays in registers across the compute stages)
+    auto piece_ok = [&](int sg, int scr, int it, int band) {
+        const int cr = scr + ROWS_PER_PASS * it;                        // cr = c * NR + ry (fp32) or ry (uint8)
         const int c = U8 ? 0 : (cr >= NR) + (cr >= 2 * NR), ry = cr - c * NR;
-        const int yin = rin0 + ry;
-        in_ok[it] = cr < NROWS && g >= 1 && g <= 28 && yin >= 0 && yin < HI;
-        const int x0 = flip ? 108 - 4 * (g - 1) : 4 * (g - 1);
-        if (!U8) {
-            vin[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (in_ok[it])
-                vin[it] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(Xv) + (size_t)src * 3 * HI * HI +
-                                                          ((size_t)c * HI + yin) * HI + x0);
-        } else {
-            win[it][0] = win[it][1] = win[it][2] = 0;
-            if (in_ok[it]) {   // uint8 HWC: 4 pixels x 3 channels = 12 contiguous bytes
-                const unsigned* pw = reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(Xv) +
-                                                                      (size_t)src * HI * HI * 3 + ((size_t)yin * HI + x0) * 3);
-                win[it][0] = pw[0]; win[it][1] = pw[1]; win[it][2] = pw[2];
+        const int yin = 2 * (band * TR - 1) - 1 + ry;                   // LDS input row 0 holds input row 2 row0 - 1
+        return cr < NROWS && sg >= 1 && sg <= 28 && yin >= 0 && yin < HI;
+    };
+    auto request = [&](int item) {
+        int ot = tid;
+        asm volatile("" : "+v"(ot));
+        const int sg = ot & 31, scr = ot >> 5;
+        const int img = item / NB, band = item - img * NB;
+        const int src = img >= n_src ? img - n_src : img;
+        const bool flip = img >= n_src;
+        const int x0 = flip ? 108 - 4 * (sg - 1) : 4 * (sg - 1);
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) {
+            const int cr = scr + ROWS_PER_PASS * it;
+            const int c = U8 ? 0 : (cr >= NR) + (cr >= 2 * NR), ry = cr - c * NR;
+            const int yin = 2 * (band * TR - 1) - 1 + ry;
+            const bool ok = piece_ok(sg, scr, it, band);
+            if (!U8) {
+                vin[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok)
+                    vin[it] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(Xv) + (size_t)src * 3 * HI * HI +
+                                                              ((size_t)c * HI + yin) * HI + x0);
+            } else {
+                win[it][0] = win[it][1] = win[it][2] = 0;
+                if (ok) {   // uint8 HWC: 4 pixels x 3 channels = 12 contiguous bytes
+                    const unsigned* pw = reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(Xv) +
+                                                                          (size_t)src * HI * HI * 3 + ((size_t)yin * HI + x0) * 3);
+                    win[it][0] = pw[0]; win[it][1] = pw[1]; win[it][2] = pw[2];
+                }
             }
         }
-    }
-    V8 w2v = {};
-    if (tid < 9 * 64 / 8) w2v = reinterpret_cast<const V8*>(W2)[tid];
-    f32x4 pv[4] = {};
-    if (tid < 16) {
-        pv[0] = reinterpret_cast<const f32x4*>(b1)[tid];
-        pv[1] = reinterpret_cast<const f32x4*>(s1)[tid];
-        pv[2] = reinterpret_cast<const f32x4*>(b2)[tid];
-        pv[3] = reinterpret_cast<const f32x4*>(s2)[tid];
-    }
-    // zero what the depthwise stage reads of the activation image but the stem stage never writes -- the border slots
-    // 0 and W + 1 of every row and the rows outside the image -- and the padding plane; planes 0-2 are written in
-    // full by the staging loop
-    for (int i = tid; i < RIN * 16; i += NT) {
-        const int ri = i >> 4, u = i & 15;
-        *reinterpret_cast<f32x4*>(es + (ri * PITCH + (u >> 3) * (W + 1)) * 128 + (u & 7) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (row0 < 0)
-        for (int i = tid; i < PITCH * 8; i += NT) reinterpret_cast<f32x4*>(es)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (row0 + RIN - 1 >= H)
-        for (int i = tid; i < PITCH * 8; i += NT)
-            reinterpret_cast<f32x4*>(es + (RIN - 1) * PITCH * 128)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < NR * PW * 2 / 16; i += NT)
-        reinterpret_cast<f32x4*>(lds + OFF_IN + 3 * NR * PW * 2)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    static_assert(9 * 64 / 8 <= NT, "one thread per 16-byte piece of the 3x3 weights");
-    if (tid < 9 * 64 / 8) reinterpret_cast<V8*>(lds + OFF_W2)[tid] = w2v;
-    if (tid < 16) {
-        reinterpret_cast<f32x4*>(lds + OFF_B1)[tid] = pv[0];
-        reinterpret_cast<f32x4*>(lds + OFF_S1)[tid] = pv[1];
-        reinterpret_cast<f32x4*>(lds + OFF_B2)[tid] = pv[2];
-        reinterpret_cast<f32x4*>(lds + OFF_S2)[tid] = pv[3];
-    }
+    };
+    // the requested rows: registers -> 16-bit LDS planes
+    auto stage = [&](int item) {
+        int ot = tid;
+        asm volatile("" : "+v"(ot));
+        const int sg = ot & 31, scr = ot >> 5;
+        const int img = item / NB, band = item - img * NB;
+        const bool flip = img >= n_src;
 #pragma unroll
-    for (int it = 0; it < IN_IT; ++it) {
-        const int g = tid & 31, cr = (tid >> 5) + ROWS_PER_PASS * it;
-        if (cr >= NROWS || g >= NG) continue;
-        if (!U8) {
-            f32x4 v = vin[it];
-            if (flip) v = f32x4{v[3], v[2], v[1], v[0]};
-            V4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
-            *reinterpret_cast<V4*>(inp + cr * PW + 4 * g) = o;
-        } else {
-            // ToTensor (/255) then Normalize ((t - 0.5) / 0.5)
-            const unsigned long long lo = (unsigned long long)win[it][0] | ((unsigned long long)win[it][1] << 32);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
+        for (int it = 0; it < IN_IT; ++it) {
+            const int cr = scr + ROWS_PER_PASS * it;
+            if (cr >= NROWS || sg >= NG) continue;
+            if (!U8) {
+                f32x4 v = vin[it];
+                if (flip) v = f32x4{v[3], v[2], v[1], v[0]};
                 V4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int byte = 3 * j + c;          // pixel j, channel c
-                    const unsigned u = byte < 8 ? (unsigned)(lo >> (8 * byte)) & 255u : (win[it][2] >> (8 * (byte - 8))) & 255u;
-                    // ((u / 255) - 0.5) / 0.5 as one FMA: after rounding to the 16-bit storage type it gives the
-                    // reference's value for every one of the 256 inputs (checked exhaustively, f16 and bf16)
-                    const float f = in_ok[it] ? fmaf((float)u, 2.0f / 255.0f, -1.0f) : 0.0f;
-                    o[flip ? 3 - j : j] = (T)f;
+                for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
+                *reinterpret_cast<V4*>(inp + cr * PW + 4 * sg) = o;
+            } else {
+                // ToTensor (/255) then Normalize ((t - 0.5) / 0.5)
+                const bool ok = piece_ok(sg, scr, it, band);
+                const unsigned long long lo = (unsigned long long)win[it][0] | ((unsigned long long)win[it][1] << 32);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    V4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int byte = 3 * j + c;          // pixel j, channel c
+                        const unsigned u = byte < 8 ? (unsigned)(lo >> (8 * byte)) & 255u : (win[it][2] >> (8 * (byte - 8))) & 255u;
+                        // ((u / 255) - 0.5) / 0.5 as one FMA: after rounding to the 16-bit storage type it gives the
+                        // reference's value for every one of the 256 inputs (checked exhaustively, f16 and bf16)
+                        const float f = ok ? fmaf((float)u, 2.0f / 255.0f, -1.0f) : 0.0f;
+                        o[flip ? 3 - j : j] = (T)f;
+                    }
+                    *reinterpret_cast<V4*>(inp + (c * NR + cr) * PW + 4 * sg) = o;
                 }
-                *reinterpret_cast<V4*>(inp + (c * NR + cr) * PW + 4 * g) = o;
             }
+        }
+    };
+    int item = blockIdx.x;
+    request(item);
+
+    // ---- once per workgroup: weights and parameters to LDS, the zero parts of both images
+    {
+        V8 wav = {};
+        static_assert(64 * 32 / 8 <= NT, "one thread per 16-byte piece of the stem weights");
+        if (tid < 64 * 32 / 8) wav = reinterpret_cast<const V8*>(WA)[tid];
+        f32x4 pv[4] = {};
+        if (tid < 16) {
+            pv[0] = reinterpret_cast<const f32x4*>(b1)[tid];
+            pv[1] = reinterpret_cast<const f32x4*>(s1)[tid];
+            pv[2] = reinterpret_cast<const f32x4*>(b2)[tid];
+            pv[3] = reinterpret_cast<const f32x4*>(s2)[tid];
+        }
+        // the border slots 0 and W + 1 of every row of the activation image (the stem stage never writes them) and
+        // the padding plane of the input
+        for (int i = tid; i < RIN * 16; i += NT) {
+            const int ri = i >> 4, u = i & 15;
+            *reinterpret_cast<f32x4*>(es + ri * SD_ROWB + (u >> 3) * (W + 1) * 128 + (u & 7) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int i = tid; i < NR * PW * 2 / 16; i += NT)
+            reinterpret_cast<f32x4*>(lds + OFF_IN + 3 * NR * PW * 2)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the stem stage's gather table: tap t = 16 s + 8 h + j of a lane -> plane c = t / 9 (3 = zero plane), ky, kx;
+        // element offset from the lane's patch origin (LDS row 2 iy, column 2 ix + 3); entry [h][8 s + j]
+        if (tid < 32) {
+            const int hh = tid >> 4, k = tid & 15, t = 16 * (k >> 3) + 8 * hh + (k & 7);
+            const int c = t / 9, rem = t - 9 * c, ky = rem / 3, kx = rem - 3 * ky;
+            reinterpret_cast<int*>(lds + OFF_TOFF)[tid] = (c * NR + ky) * PW + kx + 3;
+        }
+        // the depthwise stage's diagonal fragments: [4 p + c][lane]
+        for (int i = tid; i < 12 * 64; i += NT) {
+            const int pc = i >> 6, l = i & 63;
+            *reinterpret_cast<typename StemDwStage<T>::u32x4*>(lds + OFF_DG + i * 16) =
+                StemDwStage<T>::fragment(reinterpret_cast<const unsigned short*>(W2), pc >> 2, pc & 3, l & 15, l >> 4);
+        }
+        if (tid < 64 * 32 / 8) reinterpret_cast<V8*>(lds + OFF_WA)[tid] = wav;
+        if (tid < 16) {
+            reinterpret_cast<f32x4*>(lds + OFF_B1)[tid] = pv[0];
+            reinterpret_cast<f32x4*>(lds + OFF_S1)[tid] = pv[1];
+            reinterpret_cast<f32x4*>(lds + OFF_B2)[tid] = pv[2];
+            reinterpret_cast<f32x4*>(lds + OFF_S2)[tid] = pv[3];
         }
     }
 
-    // stem weights as MFMA A fragments: 2 tiles of 32 (permuted) output channels x 2 k-steps
-    V8 wa[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) wa[m][s] = *reinterpret_cast<const V8*>(WA + (32 * m + r) * 32 + 16 * s + 8 * h);
-
-    // the 16 taps this lane gathers: t = 16 s + 8 h + j -> plane c = t / 9 (3 = zero plane), ky, kx;
-    // element offset from the lane's patch origin (LDS row 2 iy, column 2 ix + 3)
-    int toff[2][8];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            // both halves' values are compile-time constants: one select instead of two divisions per tap
-            auto off = [](int t) { const int c = t / 9, rem = t - 9 * c, ky = rem / 3, kx = rem - 3 * ky; return (c * NR + ky) * PW + kx + 3; };
-            toff[s][j] = h ? off(16 * s + 8 + j) : off(16 * s + j);
-        }
-    __syncthreads();
-
-    // ================= stem: im2col GEMM -> PReLU -> LDS image =================
+    stage(item);
 #pragma unroll 1
-    for (int t = 0; t < MTIW; ++t) {
-        if (wave + NW * t >= MTI) break;      // wave-uniform
-        const int p = 32 * (wave + NW * t) + r;
-        const bool inb = p < PIN;
-        const int pc = inb ? p : 0;
-        const int iy = pc / W, ix = pc - iy * W;
-        const int gy = row0 + iy;
-        const bool ok = inb && (gy >= 0) && (gy < H);
-        const T* patch = inp + (2 * iy) * PW + 2 * ix;
-        V8 bfr[2];
+    for (; item < n_items; item += gridDim.x) {
+        const int img = item / NB, band = item - img * NB;
+        const int y0 = band * TR, row0 = y0 - 1;
+        const bool edge = row0 < 0 || row0 + RIN > H;
+
+        __syncthreads();
+        if (item + (int)gridDim.x < n_items) request(item + gridDim.x);      // wave-uniform; lands during the stem stage
+
+        // ================= stem: im2col GEMM -> PReLU -> LDS image =================
+        {
+            // (lane constants are rebuilt per item from an opaque copy of the lane index: kept live across the loop
+            // they would not fit the register budget of the depthwise stage)
+            int r = lane & 31, h = lane >> 5;
+            asm volatile("" : "+v"(r), "+v"(h));
+            // stem weights as MFMA A fragments: 2 tiles of 32 (permuted) output channels x 2 k-steps
+            V8 wa[2][2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bfr[s][j] = patch[toff[s][j]];
-        const int slot = iy * PITCH + ix + 1;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            f32x16 acc;
+                for (int s = 0; s < 2; ++s)
+                    wa[m][s] = *reinterpret_cast<const V8*>(lds + OFF_WA + ((32 * m + r) * 32 + 16 * s + 8 * h) * 2);
+            // the 16 taps this lane gathers, as element offsets from its patch origin (table built at set-up)
+            int toff[2][8];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + (32 * m + 16 * (q >> 1) + 8 * h + 4 * (q & 1)) * 4);
+                const i32x4 v = *reinterpret_cast<const i32x4*>(lds + OFF_TOFF + (16 * h + 4 * q) * 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[4 * q + i] = b[i];
+                for (int i = 0; i < 4; ++i) toff[q >> 1][4 * (q & 1) + i] = v[i];
             }
-            acc = mfma32(wa[m][0], bfr[0], acc);
-            acc = mfma32(wa[m][1], bfr[1], acc);
-            if (ok) {
+#pragma unroll 1
+            for (int t = 0; t < MTIW; ++t) {
+                if (wave + NW * t >= MTI) break;      // wave-uniform
+                const int p = 32 * (wave + NW * t) + r;
+                const bool inb = p < PIN;
+                const int pc = inb ? p : 0;
+                const int iy = pc / W, ix = pc - iy * W;
+                const int gy = row0 + iy;
+                const bool ok = (gy >= 0) && (gy < H);          // rows outside the image are written as zeros
+                const T* patch = inp + (2 * iy) * PW + 2 * ix;
+                V8 bfr[2];
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    V8 o;
+                for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        const f32x4 sl = *reinterpret_cast<const f32x4*>(lds + OFF_S1 + (32 * m + 16 * g + 8 * h + 4 * a) * 4);
+                    for (int j = 0; j < 8; ++j) bfr[s][j] = patch[toff[s][j]];
+                const int sx = ix + 1;                 // slot of the pixel in its image row
+                char* const px = es + iy * SD_ROWB + sx * 128;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float v = acc[4 * (2 * g + a) + i];
-                            o[4 * a + i] = (T)fmaf(neg_part(v), sl[i], v);   // PReLU: sl = slope - 1
+                for (int m = 0; m < 2; ++m) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + (32 * m + 16 * (q >> 1) + 8 * h + 4 * (q & 1)) * 4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[4 * q + i] = b[i];
+                    }
+                    acc = mfma32(wa[m][0], bfr[0], acc);
+                    acc = mfma32(wa[m][1], bfr[1], acc);
+                    if (inb) {
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            V8 o;
+#pragma unroll
+                            for (int a = 0; a < 2; ++a) {
+                                const f32x4 sl = *reinterpret_cast<const f32x4*>(lds + OFF_S1 + (32 * m + 16 * g + 8 * h + 4 * a) * 4);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const float v = acc[4 * (2 * g + a) + i];
+                                    o[4 * a + i] = (T)fmaf(neg_part(v), sl[i], v);   // PReLU: sl = slope - 1
+                                }
+                            }
+                            if (edge) {                 // wave-uniform: only the first and last band have such rows
+                                if (!ok) o = V8{};
+                            }
+                            const int u = 4 * m + 2 * g + h;       // channels [8u, 8u+8)
+                            *reinterpret_cast<V8*>(px + ((u ^ (sx & 7)) << 4)) = o;
                         }
                     }
-                    const int u = 4 * m + 2 * g + h;       // channels [8u, 8u+8)
-                    *reinterpret_cast<V8*>(es + slot * 128 + ((u ^ (slot & 7)) << 4)) = o;
                 }
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        if (item + (int)gridDim.x < n_items) stage(item + gridDim.x);        // the input planes are free again
+        __builtin_amdgcn_sched_barrier(0);    // the depthwise stage needs the registers the staged rows held
 
-    // ================= depthwise 3x3 + PReLU from the LDS image -> NHWC =================
-    if (wave < W / 8) {                       // wave-uniform; wave w owns output columns 8 w .. 8 w + 7 of every row
-        // this lane's column and its 8 channels; everything that depends only on them stays in registers
-        StemDwStage<T, TR> dw;
-        const int dpx = lane >> 3, du = lane & 7;
-        const int x = 8 * wave + dpx;
+        // ================= depthwise 3x3 + PReLU from the LDS image -> NHWC =================
+        if (wave < W / 8) {                       // wave-uniform; wave w owns output columns 8 w .. 8 w + 7 of every row
+            StemDwStage<T> dw;
+            int m = lane & 15, g = lane >> 4;
+            asm volatile("" : "+v"(m), "+v"(g));
+            {
+                uint32_t msk_unused[4];
+                StemDwStage<T>::lane_masks(m, g, msk_unused, dw.idx);
+            }
+            dw.dga = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + OFF_DG + (16 * g + m) * 16;
+            // B side: pixel m of tile t = (row t + 2 (m >> 3), column 8 w + (m & 7)); tap slot g = tap column
+            // min(g, 2); output column x reads slots x .. x + 2
+            const int sx = 8 * wave + (m & 7) + (g < 2 ? g : 2);
+            const int tap = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + 2 * (m >> 3) * SD_ROWB + sx * 128;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) dw.wk[k] = *reinterpret_cast<const V8*>(lds + OFF_W2 + (k * 64 + 8 * du) * 2);
-        dw.b2a = *reinterpret_cast<const f32x4*>(lds + OFF_B2 + 32 * du);
-        dw.b2b = *reinterpret_cast<const f32x4*>(lds + OFF_B2 + 32 * du + 16);
-        dw.s2a = *reinterpret_cast<const f32x4*>(lds + OFF_S2 + 32 * du);
-        dw.s2b = *reinterpret_cast<const f32x4*>(lds + OFF_S2 + 32 * du + 16);
+            for (int u = 0; u < 8; ++u) dw.ta[u] = tap + ((u ^ (sx & 7)) << 4);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int col = x + kx;           // LDS column of tap kx (column 0 is the left border)
-            dw.eb[kx] = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + col * 128 + ((du ^ (col & 7)) << 4);
+            for (int c = 0; c < 4; ++c) {
+                dw.bias[c] = *reinterpret_cast<const f32x4*>(lds + OFF_B2 + (16 * c + 4 * g) * 4);
+                dw.slope[c] = *reinterpret_cast<const f32x4*>(lds + OFF_S2 + (16 * c + 4 * g) * 4);
+            }
+            // after the lane swap: rows g = 0, 2 hold unit 4 h + (g >> 1), rows g = 1, 3 unit 4 h + 2 + (g >> 1)
+            dw.out = O + ((size_t)img * H * W + (size_t)(y0 + 2 * (m >> 3)) * W + 8 * wave + (m & 7)) * 64 + 16 * (g & 1) + 8 * (g >> 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dw.preamble();
+            dw.run();
         }
-        dw.out = O + ((size_t)img * H * W + (size_t)y0 * W + x) * 64 + 8 * du;
-        dw.preamble();
-        dw.run();
     }
 }
 
 template <typename T, bool U8, int TR, int NW, int MINW>
 static int launch_stemdw_cfg(const StemDwParams& p, const void* x, int n_src, void* out, int B, hipStream_t s) {
-    constexpr int lds = (TR + 2) * SD_PITCH * 128 + 4 * (2 * TR + 5) * 120 * 2 + 9 * 64 * 2 + 4 * 256;
+    constexpr int lds = (TR + 2) * SD_ROWB + 4 * (2 * TR + 5) * 120 * 2 + 9 * 64 * 2 + 4 * 256 + 64 * 32 * 2 + 12 * 64 * 16 + 128;
     auto kern = stemdw_kernel<T, U8, TR, NW, MINW>;
     static std::atomic<uint64_t> lds_set;   // per instantiation: devices whose LDS limit is raised
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set)) return rc;
-    hipLaunchKernelGGL(kern, dim3(56 / TR, B), dim3(NW * 64), lds, s, x, n_src, (const T*)p.wa, p.b1, p.s1, (const T*)p.w2,
-                       p.b2, p.s2, (T*)out);
+    static std::atomic<int> slots_of[64];   // resident workgroups, per device (0 = not asked yet)
+    int dev = 0;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set, &dev)) return rc;
+    int slots = dev < 64 ? slots_of[dev].load(std::memory_order_relaxed) : 0;
+    if (slots == 0) {
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NW * 64, (size_t)lds) != hipSuccess || per_cu <= 0)
+            per_cu = 1;
+        slots = cus * per_cu;
+        if (dev < 64) slots_of[dev].store(slots, std::memory_order_relaxed);
+    }
+    // one workgroup per resident slot, each walking over its (image, band) items in equal shares
+    const int items = B * (56 / TR);
+    const int per = (items + slots - 1) / slots;
+    const int groups = (items + per - 1) / per;
+    hipLaunchKernelGGL(kern, dim3(groups), dim3(NW * 64), lds, s, x, n_src, items, (const T*)p.wa, p.b1, p.s1,
+                       (const T*)p.w2, p.b2, p.s2, (T*)out);
     FRA_HIP(hipGetLastError());
     return FRA_OK;
 }
