@@ -211,7 +211,7 @@ bool rblock_chain_pays(int c, int cexp, int h, int B);
 // fused head: stem conv (3->64, 3x3 s2, PReLU) + depthwise 3x3 (64 ch, PReLU) -> out T NHWC [B,56,56,64].
 // x: n_src crops, f32 NCHW in [-1,1] or (x_is_u8) uint8 HWC; images n_src..B-1 are mirrored copies of images 0..B-n_src-1
 struct StemDwParams {
-    const void* wa;     // T [64][32]: row perm_pos(oc) holds output channel oc, columns = taps (c*9+ky*3+kx), 27..31 zero
+    const void* wa;     // T [64][32]: row 16 (2 (U >> 2) + a) + 4 (U & 3) + i holds output channel 8 U + 4 a + i; columns = taps (c*9+ky*3+kx), 27..31 zero
     const float* b1;    // [64] natural order
     const float* s1;    // [64] PReLU slope MINUS ONE
     const void* w2;     // T [9][64] tap-major depthwise weights

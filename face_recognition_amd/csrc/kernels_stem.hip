@@ -156,8 +156,8 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, int n_items, const T*
     constexpr int H = 56, W = 56, HI = 112, NB = H / TR;
     constexpr int RIN = TR + 2;
     constexpr int PIN = RIN * W;
-    constexpr int MTI = (PIN + 31) / 32;
-    constexpr int MTIW = (MTI + NW - 1) / NW;
+    static_assert(PIN % 16 == 0, "stem stage: whole tiles of 16 pixels");
+    constexpr int MTI = PIN / 16;
     static_assert(W % 8 == 0 && W / 8 <= NW && SD_ROWB >= (W + 2) * 128 && TR == 4, "depthwise stage: one wave per 8-pixel column group, two tiles of two rows");
     constexpr int ES_BYTES = RIN * SD_ROWB;
     // staged input: 4 planes (3 channels + one all-zero plane for the 5 padding taps) of NR rows x PW columns;
@@ -285,11 +285,10 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, int n_items, const T*
         }
         for (int i = tid; i < NR * PW * 2 / 16; i += NT)
             reinterpret_cast<f32x4*>(lds + OFF_IN + 3 * NR * PW * 2)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // the stem stage's gather table: tap t = 16 s + 8 h + j of a lane -> plane c = t / 9 (3 = zero plane), ky, kx;
-        // element offset from the lane's patch origin (LDS row 2 iy, column 2 ix + 3); entry [h][8 s + j]
+        // the stem stage's gather table: tap t -> plane c = t / 9 (3 = zero plane), ky, kx; element offset from a
+        // lane's patch origin (LDS row 2 iy, column 2 ix + 3).  Lane group g gathers taps 8 g .. 8 g + 7
         if (tid < 32) {
-            const int hh = tid >> 4, k = tid & 15, t = 16 * (k >> 3) + 8 * hh + (k & 7);
-            const int c = t / 9, rem = t - 9 * c, ky = rem / 3, kx = rem - 3 * ky;
+            const int t = tid, c = t / 9, rem = t - 9 * c, ky = rem / 3, kx = rem - 3 * ky;
             reinterpret_cast<int*>(lds + OFF_TOFF)[tid] = (c * NR + ky) * PW + kx + 3;
         }
         // the depthwise stage's diagonal fragments: [4 p + c][lane]
@@ -318,74 +317,59 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, int n_items, const T*
         if (item + (int)gridDim.x < n_items) request(item + gridDim.x);      // wave-uniform; lands during the stem stage
 
         // ================= stem: im2col GEMM -> PReLU -> LDS image =================
+        // 16x16x32 MFMAs: one instruction covers the 27 taps (K padded to 32) for 16 output channels and 16 pixels.
+        // Weight row 16 n + 4 g + i holds channel 8 (4 (n >> 1) + g) + 4 (n & 1) + i, so a lane's results of row
+        // tiles 2 v and 2 v + 1 are the 8 consecutive channels of unit 4 v + g.  21 tiles of 16 pixels over 8 waves.
         {
             // (lane constants are rebuilt per item from an opaque copy of the lane index: kept live across the loop
             // they would not fit the register budget of the depthwise stage)
-            int r = lane & 31, h = lane >> 5;
-            asm volatile("" : "+v"(r), "+v"(h));
-            // stem weights as MFMA A fragments: 2 tiles of 32 (permuted) output channels x 2 k-steps
-            V8 wa[2][2];
+            int m = lane & 15, g = lane >> 4;
+            asm volatile("" : "+v"(m), "+v"(g));
+            V8 wa[4];
+            f32x4 bq[4], sq[4];             // bias and slope - 1 of the lane's channels, per row tile
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int n = 0; n < 4; ++n) {
+                wa[n] = *reinterpret_cast<const V8*>(lds + OFF_WA + ((16 * n + m) * 32 + 8 * g) * 2);
+                bq[n] = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + (8 * (4 * (n >> 1) + g) + 4 * (n & 1)) * 4);
+                sq[n] = *reinterpret_cast<const f32x4*>(lds + OFF_S1 + (8 * (4 * (n >> 1) + g) + 4 * (n & 1)) * 4);
+            }
+            int toff[8];                    // the 8 taps this lane gathers, as element offsets from its patch origin
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    wa[m][s] = *reinterpret_cast<const V8*>(lds + OFF_WA + ((32 * m + r) * 32 + 16 * s + 8 * h) * 2);
-            // the 16 taps this lane gathers, as element offsets from its patch origin (table built at set-up)
-            int toff[2][8];
+            for (int q = 0; q < 2; ++q) {
+                const i32x4 v = *reinterpret_cast<const i32x4*>(lds + OFF_TOFF + (8 * g + 4 * q) * 4);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const i32x4 v = *reinterpret_cast<const i32x4*>(lds + OFF_TOFF + (16 * h + 4 * q) * 4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) toff[q >> 1][4 * (q & 1) + i] = v[i];
+                for (int i = 0; i < 4; ++i) toff[4 * q + i] = v[i];
             }
 #pragma unroll 1
-            for (int t = 0; t < MTIW; ++t) {
-                if (wave + NW * t >= MTI) break;      // wave-uniform
-                const int p = 32 * (wave + NW * t) + r;
-                const bool inb = p < PIN;
-                const int pc = inb ? p : 0;
-                const int iy = pc / W, ix = pc - iy * W;
+            for (int tt = wave; tt < MTI; tt += NW) {
+                const int p = 16 * tt + m;
+                const int iy = p / W, ix = p - iy * W;
                 const int gy = row0 + iy;
                 const bool ok = (gy >= 0) && (gy < H);          // rows outside the image are written as zeros
                 const T* patch = inp + (2 * iy) * PW + 2 * ix;
-                V8 bfr[2];
+                V8 bfr;
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) bfr[s][j] = patch[toff[s][j]];
+                for (int j = 0; j < 8; ++j) bfr[j] = patch[toff[j]];
                 const int sx = ix + 1;                 // slot of the pixel in its image row
                 char* const px = es + iy * SD_ROWB + sx * 128;
+                f32x4 acc[4];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    f32x16 acc;
+                for (int n = 0; n < 4; ++n) acc[n] = mfma16(wa[n], bfr, bq[n]);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + (32 * m + 16 * (q >> 1) + 8 * h + 4 * (q & 1)) * 4);
+                for (int v = 0; v < 2; ++v) {
+                    V8 o;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[4 * q + i] = b[i];
-                    }
-                    acc = mfma32(wa[m][0], bfr[0], acc);
-                    acc = mfma32(wa[m][1], bfr[1], acc);
-                    if (inb) {
+                    for (int a = 0; a < 2; ++a)
 #pragma unroll
-                        for (int g = 0; g < 2; ++g) {
-                            V8 o;
-#pragma unroll
-                            for (int a = 0; a < 2; ++a) {
-                                const f32x4 sl = *reinterpret_cast<const f32x4*>(lds + OFF_S1 + (32 * m + 16 * g + 8 * h + 4 * a) * 4);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    const float v = acc[4 * (2 * g + a) + i];
-                                    o[4 * a + i] = (T)fmaf(neg_part(v), sl[i], v);   // PReLU: sl = slope - 1
-                                }
-                            }
-                            if (edge) {                 // wave-uniform: only the first and last band have such rows
-                                if (!ok) o = V8{};
-                            }
-                            const int u = 4 * m + 2 * g + h;       // channels [8u, 8u+8)
-                            *reinterpret_cast<V8*>(px + ((u ^ (sx & 7)) << 4)) = o;
+                        for (int i = 0; i < 4; ++i) {
+                            const float x = acc[2 * v + a][i];
+                            o[4 * a + i] = (T)fmaf(neg_part(x), sq[2 * v + a][i], x);   // PReLU: sq = slope - 1
                         }
+                    if (edge) {                 // wave-uniform: only the first and last band have such rows
+                        if (!ok) o = V8{};
                     }
+                    const int u = 4 * v + g;       // channels [8u, 8u+8)
+                    *reinterpret_cast<V8*>(px + ((u ^ (sx & 7)) << 4)) = o;
                 }
             }
         }

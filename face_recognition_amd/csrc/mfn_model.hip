@@ -311,8 +311,10 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
             if ((rc = bn_fold(m, "conv1.bn", 64, scale, shift))) return rc;
             if ((rc = fetch(m, "conv1.prelu.weight", 64, &a))) return rc;
             for (int oc = 0; oc < 64; ++oc) {
+                // unit U = oc / 8 = 4 v + g, channel 4 a + i of it: MFMA row tile 2 v + a, row 4 g + i
+                const int U = oc >> 3, row = 16 * (2 * (U >> 2) + ((oc >> 2) & 1)) + 4 * (U & 3) + (oc & 3);
                 for (int t = 0; t < 32; ++t)
-                    wa[perm_pos(oc) * 32 + t] = to16(dt, t < 27 ? (float)(w[oc * 27 + t] * scale[oc]) : 0.0f);
+                    wa[row * 32 + t] = to16(dt, t < 27 ? (float)(w[oc * 27 + t] * scale[oc]) : 0.0f);
                 b1[oc] = (float)shift[oc];
                 s1[oc] = a[oc] - 1.0f;
             }
