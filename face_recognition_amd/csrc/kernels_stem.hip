@@ -59,8 +59,9 @@ template <typename T> struct StemDwStage {
     V8 er[SD_RING][2];
     V8 dg[SD_RING + 1];                   // the diagonal of (window row a, chunk c) arrives with set (c, a); tile 1 uses it one set later
     int idx;                              // positions of the sparse fragment's elements
-    f32x4 bias[4], slope[4];              // channels 16 c + 4 g .. + 3; slope holds slope - 1
-    f32x4 acc[2];
+    f32x4 slope[4];                       // channels 16 c + 4 g .. + 3; slope - 1
+    f32x4 acc[2][2];                      // [chunk parity][tile]: the bias of chunk c arrives in them with set (c, 0)
+    int pb;                               // LDS address of the bias quad of channels 4 g ..; + 64 c
     int dga;                              // LDS address of this lane's diagonal fragment (0, 0); + ((4 p + c) * 64) * 16
     u32x2 held[2];                        // the even chunk's rounded results, per tile
     int ta[8];                            // LDS address of unit u of this lane's tap column, set 0
@@ -87,7 +88,7 @@ template <typename T> struct StemDwStage {
         const uint32_t w = even | ((g & 1) ? 0u : odd << 16);
         return u32x4{w & msk[0], w & msk[1], w & msk[2], w & msk[3]};
     }
-    static constexpr int reads_of(int S) { return S % 4 < 3 ? 3 : 2; }
+    static constexpr int reads_of(int S) { return S % 4 == 0 ? 5 : S % 4 < 3 ? 3 : 2; }
     static constexpr int reads_after(int S) {        // LDS reads issued after set S's when the wave waits for it
         int n = 0;
         for (int k = S + 1; k <= S + SD_PD && k < SETS; ++k) n += reads_of(k);
@@ -98,6 +99,10 @@ template <typename T> struct StemDwStage {
         STEM_LDS_READ16(er[S % SD_RING][0], ta[2 * c], a * SD_ROWB);
         STEM_LDS_READ16(er[S % SD_RING][1], ta[2 * c + 1], a * SD_ROWB);
         if constexpr (a < 3) STEM_LDS_READ16(dg[S % (SD_RING + 1)], dga, ((4 * a + c) * 64) * 16);
+        if constexpr (a == 0) {
+            STEM_LDS_READ16(acc[c & 1][0], pb, 64 * c);
+            STEM_LDS_READ16(acc[c & 1][1], pb, 64 * c);
+        }
     }
     template <int S = 0> __device__ __forceinline__ void preamble() {
         if constexpr (S < SD_PD) { issue<S>(); preamble<S + 1>(); }
@@ -106,7 +111,7 @@ template <typename T> struct StemDwStage {
     template <int C, int TILE> __device__ __forceinline__ void finish() {
         V4 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (T)fmaf(neg_part(acc[TILE][i]), slope[C][i], acc[TILE][i]);
+        for (int i = 0; i < 4; ++i) o[i] = (T)fmaf(neg_part(acc[C & 1][TILE][i]), slope[C][i], acc[C & 1][TILE][i]);
         const u32x2 w = __builtin_bit_cast(u32x2, o);
         if constexpr (C % 2 == 0) {
             held[TILE] = w;
@@ -116,9 +121,6 @@ template <typename T> struct StemDwStage {
             const u32x2 s0 = __builtin_amdgcn_permlane16_swap(held[TILE][0], w[0], false, false);
             const u32x2 s1 = __builtin_amdgcn_permlane16_swap(held[TILE][1], w[1], false, false);
             const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
-#ifdef STEM_ABL_NOSTORE
-            if (acc[TILE][0] == 12345.678f)
-#endif
             *reinterpret_cast<u32x4*>(out + (size_t)TILE * 56 * 64 + 32 * (C / 2)) = v;
         }
     }
@@ -126,14 +128,14 @@ template <typename T> struct StemDwStage {
         if constexpr (S < SETS) {
             constexpr int c = S / 4, a = S % 4, slot = S % SD_RING, ds = S % (SD_RING + 1), dp = (S + SD_RING) % (SD_RING + 1);
             if constexpr (S + SD_PD < SETS) issue<S + SD_PD>();
-            if constexpr (a < 3)
+            if constexpr (a == 0)
+                asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(er[slot][0]), "+v"(er[slot][1]), "+v"(dg[ds]), "+v"(acc[c & 1][0]), "+v"(acc[c & 1][1]) : "n"(reads_after(S)));
+            else if constexpr (a < 3)
                 asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(er[slot][0]), "+v"(er[slot][1]), "+v"(dg[ds]) : "n"(reads_after(S)));
             else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(er[slot][0]), "+v"(er[slot][1]) : "n"(reads_after(S)));
             const V16 e = __builtin_shufflevector(er[slot][0], er[slot][1], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-            if constexpr (a == 0) acc[0] = bias[c];
-            if constexpr (a == 1) acc[1] = bias[c];
-            if constexpr (a <= 2) acc[0] = smfma16(dg[ds], e, acc[0], idx);
-            if constexpr (a >= 1) acc[1] = smfma16(dg[dp], e, acc[1], idx);     // window row a - 1: the previous set's diagonal
+            if constexpr (a <= 2) acc[c & 1][0] = smfma16(dg[ds], e, acc[c & 1][0], idx);
+            if constexpr (a >= 1) acc[c & 1][1] = smfma16(dg[dp], e, acc[c & 1][1], idx);     // window row a - 1: the previous set's diagonal
             if constexpr (a == 3) {
                 finish<c, 0>();
                 finish<c, 1>();
@@ -311,10 +313,16 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, int n_items, const T*
     for (; item < n_items; item += gridDim.x) {
         const int img = item / NB, band = item - img * NB;
         const int y0 = band * TR, row0 = y0 - 1;
-        const bool edge = row0 < 0 || row0 + RIN > H;
 
         __syncthreads();
         if (item + (int)gridDim.x < n_items) request(item + gridDim.x);      // wave-uniform; lands during the stem stage
+        // the first band's row above the image and the last band's row below it: zeros, which the stem stage (it
+        // skips pixels outside the image) leaves alone; the previous item's depthwise stage is done with the row
+        if (row0 < 0)
+            for (int i = tid; i < SD_ROWB / 16; i += NT) reinterpret_cast<f32x4*>(es)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row0 + RIN > H)
+            for (int i = tid; i < SD_ROWB / 16; i += NT)
+                reinterpret_cast<f32x4*>(es + (RIN - 1) * SD_ROWB)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         // ================= stem: im2col GEMM -> PReLU -> LDS image =================
         // 16x16x32 MFMAs: one instruction covers the 27 taps (K padded to 32) for 16 output channels and 16 pixels.
@@ -345,7 +353,7 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, int n_items, const T*
                 const int p = 16 * tt + m;
                 const int iy = p / W, ix = p - iy * W;
                 const int gy = row0 + iy;
-                const bool ok = (gy >= 0) && (gy < H);          // rows outside the image are written as zeros
+                const bool ok = (gy >= 0) && (gy < H);          // rows outside the image hold zeros already
                 const T* patch = inp + (2 * iy) * PW + 2 * ix;
                 V8 bfr;
 #pragma unroll
@@ -365,11 +373,8 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, int n_items, const T*
                             const float x = acc[2 * v + a][i];
                             o[4 * a + i] = (T)fmaf(neg_part(x), sq[2 * v + a][i], x);   // PReLU: sq = slope - 1
                         }
-                    if (edge) {                 // wave-uniform: only the first and last band have such rows
-                        if (!ok) o = V8{};
-                    }
                     const int u = 4 * v + g;       // channels [8u, 8u+8)
-                    *reinterpret_cast<V8*>(px + ((u ^ (sx & 7)) << 4)) = o;
+                    if (ok) *reinterpret_cast<V8*>(px + ((u ^ (sx & 7)) << 4)) = o;
                 }
             }
         }
@@ -387,6 +392,7 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, int n_items, const T*
                 StemDwStage<T>::lane_masks(m, g, msk_unused, dw.idx);
             }
             dw.dga = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + OFF_DG + (16 * g + m) * 16;
+            dw.pb = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + OFF_B2 + 16 * g;
             // B side: pixel m of tile t = (row t + 2 (m >> 3), column 8 w + (m & 7)); tap slot g = tap column
             // min(g, 2); output column x reads slots x .. x + 2
             const int sx = 8 * wave + (m & 7) + (g < 2 ? g : 2);
@@ -395,7 +401,6 @@ void stemdw_kernel(const void* __restrict__ Xv, int n_src, int n_items, const T*
             for (int u = 0; u < 8; ++u) dw.ta[u] = tap + ((u ^ (sx & 7)) << 4);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                dw.bias[c] = *reinterpret_cast<const f32x4*>(lds + OFF_B2 + (16 * c + 4 * g) * 4);
                 dw.slope[c] = *reinterpret_cast<const f32x4*>(lds + OFF_S2 + (16 * c + 4 * g) * 4);
             }
             // after the lane swap: rows g = 0, 2 hold unit 4 h + (g >> 1), rows g = 1, 3 unit 4 h + 2 + (g >> 1)
