@@ -135,11 +135,33 @@ extern "C" int fra_dbg_read(void* dst, size_t bytes) {
 #define RB_SPIN_LIMIT (1 << 20)   // polls (some 0.1 s) after which a wait gives up: wrong results instead of a wave that never ends
 #endif
 // whole-image workgroups keep TWO activation images (slices alternate) and a block of flag words
-template <int C, int CEXP, int H, int TR> constexpr int rblock_lds_bytes() {
-    return ((TR == H && RB_FLAGS) ? 2 : 1) * (TR + 2) * block_pitch<H, 1>() * 144 + 2 * RbPkg<C>::BYTES + ((TR == H && RB_FLAGS) ? 128 : 0);
+//
+// G > 1 (7 x 7 maps): a workgroup owns G whole images at a time, STACKED so that its waves have tiles to work on.  An
+// image is 7 rows of 8 slots (7 pixels and a border slot that is the next row's left border as well), images are 64
+// slots apart: the 9 slots between two images are the lower border row of the one and the upper border row of the
+// other.  The two activation image sets are G * 64 slots apart for the same reason; 16 slots follow the second one
+// (its last border row, and the reads of lanes that have no pixel).
+template <int H, int TR, int G> constexpr int rb_es_bytes() {
+    return G > 1 ? G * 64 * 144 : (TR + 2) * block_pitch<H, 1>() * 144;
+}
+// main tiles (expand input == project output) of a workgroup: whole rows, padded to 8, 16 or 32 lanes, 32 lanes per tile
+template <int H, int TR, int G> constexpr int rb_main_tiles() {
+    constexpr int rpt = 32 / (H <= 8 ? 8 : (H <= 16 ? 16 : 32));
+    return G > 1 ? (G / 2 * H + 1) / 2 : (TR + rpt - 1) / rpt;
+}
+// flags instead of barriers: whole images, one tile per wave (no two waves sharing a tile) and a wave to spare
+template <int H, int TR, int NW, int G> constexpr bool rb_flags() {
+    return TR == H && RB_FLAGS && rb_main_tiles<H, TR, G>() > NW / 2 && rb_main_tiles<H, TR, G>() < NW;
+}
+template <int H, int TR, int NW, int G> constexpr int rb_images_bytes() {
+    return G > 1 ? (2 * rb_es_bytes<H, TR, G>() + 16 * 144 + 1023) / 1024 * 1024
+                 : (rb_flags<H, TR, NW, G>() ? 2 : 1) * rb_es_bytes<H, TR, G>();
+}
+template <int C, int CEXP, int H, int TR, int NW, int G = 1> constexpr int rblock_lds_bytes() {
+    return rb_images_bytes<H, TR, NW, G>() + 2 * RbPkg<C>::BYTES + (rb_flags<H, TR, NW, G>() ? 128 : 0);
 }
 
-template <typename T, int C, int CEXP, int H, int TR, int NW>
+template <typename T, int C, int CEXP, int H, int TR, int NW, int G = 1>
 __global__ __launch_bounds__(NW * 64, 2)
 void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk) {
     typedef typename vec8<T>::type V8;
@@ -150,19 +172,28 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     constexpr int RIN = TR + 2;                            // LDS rows: band rows + one row above and below
     // a tile is RPT whole rows, each padded to POW (a power of two) lanes
     constexpr int POW = W <= 8 ? 8 : (W <= 16 ? 16 : 32), RPT = 32 / POW;
-    constexpr int MTO = (TR + RPT - 1) / RPT;              // main tiles: expand input == project output
+    // STACK: subtile st of every tile belongs to images st GP .. st GP + GP - 1 of the workgroup's G, tile t to rows
+    // 2 t, 2 t + 1 of those GP images' 7 GP rows (two rows of 7 pixels per 16-lane subtile)
+    constexpr bool STACK = G > 1;
+    constexpr int GP = STACK ? G / 2 : 1;
+    constexpr int MTO = rb_main_tiles<H, TR, G>();         // main tiles: expand input == project output
+    static_assert(MTO == (STACK ? (GP * H + 1) / 2 : (TR + RPT - 1) / RPT), "tiles of whole rows");
     constexpr int HT = WHOLE ? 0 : (RPT >= 2 ? 1 : 2);     // halo tiles (rows y0 - 1 and y0 + TR)
     constexpr int MTI = MTO + HT;
     constexpr int KS = C / 32, NT16 = C / 16, NCH = CEXP / 64;
-    constexpr int PITCH = block_pitch<H, 1>(), SLOT = 144;
-    constexpr int ES_BYTES = RIN * PITCH * SLOT;
+    constexpr int PITCH = STACK ? W + 1 : block_pitch<H, 1>(), SLOT = 144;
+    constexpr int ES_BYTES = rb_es_bytes<H, TR, G>();
+    static_assert(STACK || ES_BYTES == RIN * PITCH * SLOT, "band rows and their borders");
     // FL: no workgroup-wide barriers in the slice loop.  A wave's expand stage writes its tile's rows, its depthwise
     // stage reads those and the two neighbouring tiles' rows: it waits for those two waves only (flags in LDS), and
     // with two activation images (slice parity) a wave may expand the next slice while its neighbours still read this
     // one.  The tile-less last wave copies the weight packages and tells the others when one has landed.
-    constexpr bool FL = WHOLE && RB_FLAGS;
+    constexpr bool FL = rb_flags<H, TR, NW, G>();
     constexpr int NIMG = FL ? 2 : 1;
-    constexpr int OFF_PKG = NIMG * ES_BYTES, OFF_FLAGS = OFF_PKG + 2 * PK::BYTES;
+    constexpr int IMG_BYTES = rb_images_bytes<H, TR, NW, G>();
+    constexpr int OFF_PKG = IMG_BYTES, OFF_FLAGS = OFF_PKG + 2 * PK::BYTES;
+    static_assert(!STACK || (FL && H == 7 && (G == 2 || G == 4)), "stacked images: 7 x 7 maps, whole-image workgroups with flags");
+    static_assert(IMG_BYTES >= NIMG * ES_BYTES, "both activation images fit");
     constexpr int LDS_BYTES = OFF_FLAGS + (FL ? 128 : 0);
     constexpr int MTIW = (MTI + NW - 1) / NW;              // input tiles per wave
     // with at most NW / 2 input tiles two waves share one and expand two of the slice's four channel tiles each
@@ -175,7 +206,7 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     constexpr bool SSPLIT = ESPLIT && 4 * MTO <= NW;
     constexpr int NSUB = SSPLIT ? 1 : 2;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static_assert(LDS_BYTES == rblock_lds_bytes<C, CEXP, H, TR>(), "the launcher's LDS size is this map's");
+    static_assert(LDS_BYTES == rblock_lds_bytes<C, CEXP, H, TR, NW, G>(), "the launcher's LDS size is this map's");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -201,7 +232,7 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
 #endif
 
     // the activation image starts as zeros: border slots and out-of-image rows are never written afterwards
-    for (int i = tid; i < NIMG * ES_BYTES / 16; i += NW * 64) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < IMG_BYTES / 16; i += NW * 64) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // flags (FL): exp_done[w] / dw_done[w] = slices wave w has expanded / finished reading, pkg_ready = packages landed
     volatile int* exp_done = reinterpret_cast<volatile int*>(lds + OFF_FLAGS);
     volatile int* dw_done = exp_done + 8;
@@ -211,12 +242,23 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     // ---- this lane's pixels: tile ti, subtile st -> LDS slot and offset inside an image -------------------------
     const int we = ESPLIT ? (wave & (MTIP - 1)) : wave, en = ESPLIT ? wave / MTIP : 0;   // wave-uniform
     int lds_px[MTIW][2];   // LDS byte address of the lane's 32 bytes (positions 16 g ..) of the pixel slot; -1 = no pixel
-    int x_off[MTIW][2];    // element offset of the lane's first channel (4 g) of that pixel inside an image
+    int x_off[MTIW][2];    // element offset of the lane's first channel (4 g) of that pixel inside an image (STACK: inside the G images)
+    int img_of[MTIW][2];   // (STACK) which of the workgroup's G images the pixel belongs to
 #pragma unroll
     for (int tt = 0; tt < MTIW; ++tt)
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             const int ti = we + NW * tt;
+            img_of[tt][st] = 0;
+            if constexpr (STACK) {
+                const int pr = 2 * ti + (m16 >> 3), xx = m16 & 7;      // row among the 7 GP rows of the subtile's images
+                const int gi = st * GP + pr / H, r = pr % H;
+                const bool ok = ti < MTO && pr < GP * H && xx < W;
+                lds_px[tt][st] = ok ? (gi * 64 + PITCH + 1 + r * PITCH + xx) * SLOT + 32 * g4 : -1;
+                x_off[tt][st] = ok ? ((gi * H + r) * W + xx) * C + 4 * g4 : 4 * g4;
+                if (ok) img_of[tt][st] = gi;
+                continue;
+            }
             int lr, xx, gy;
             bool ok;
             const int rr = POW == 32 ? 0 : (POW == 16 ? st : 2 * st + (m16 >> 3));
@@ -240,30 +282,39 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     // input fragments = B operand of the expand GEMM = the shortcut; element j of k-step ks is channel
     // 32 ks + 4 g + j (j < 4) or 32 ks + 16 + 4 g + (j - 4)
     V8 xf[MTIW][2][KS];
+    // (STACK: `img` counts groups of G images; a lane whose image lies beyond the batch reads its pixel of the group's first one)
     auto load_x = [&](int img) {
-        const T* Ximg = X + (size_t)img * H * W * C;
+        const T* Ximg = X + (size_t)img * G * H * W * C;
 #pragma unroll
         for (int tt = 0; tt < MTIW; ++tt)
 #pragma unroll
-            for (int st = 0; st < 2; ++st)
+            for (int st = 0; st < 2; ++st) {
+                int off = x_off[tt][st];
+                if constexpr (STACK)
+                    if (img * G + img_of[tt][st] >= B) off -= img_of[tt][st] * H * W * C;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const V4 lo = *reinterpret_cast<const V4*>(Ximg + x_off[tt][st] + 32 * ks);
-                    const V4 hi = *reinterpret_cast<const V4*>(Ximg + x_off[tt][st] + 32 * ks + 16);
+                    const V4 lo = *reinterpret_cast<const V4*>(Ximg + off + 32 * ks);
+                    const V4 hi = *reinterpret_cast<const V4*>(Ximg + off + 32 * ks + 16);
                     xf[tt][st][ks] = V8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
+            }
     };
 
     // ---- depthwise / project side: wave wt owns output tile wt (its own main input tile), or one subtile of it --
     const int wt = SSPLIT ? we : wave;
     const bool dw_active = SSPLIT ? (we < MTO && en < 2) : (wt < MTO);
-    constexpr int ST1 = POW == 32 ? 16 * SLOT : (16 / POW) * PITCH * SLOT;
+    constexpr int ST1 = STACK ? GP * 64 * SLOT : (POW == 32 ? 16 * SLOT : (16 / POW) * PITCH * SLOT);
     static_assert(ST1 + 2 * PITCH * SLOT + 112 < 65536, "tap offsets must fit the instruction's offset field");
     int tb;               // LDS byte address of this lane's tap (0, min(g, 2)) (DwStage::tb)
     {
         const int oy = wt * RPT + m16 / POW, ox = m16 % POW;
         const int sub = SSPLIT ? en * ST1 : 0;                                 // (SSPLIT) this wave's subtile
         tb = (oy * PITCH + ox + (g4 < 2 ? g4 : 2)) * SLOT + sub;
+        if constexpr (STACK) {                             // pixel slot less one row and one slot
+            const int pr = 2 * wt + (m16 >> 3);
+            tb = ((pr / H) * 64 + (pr % H) * PITCH + (m16 & 7) + (g4 < 2 ? g4 : 2)) * SLOT;
+        }
     }
     f32x4 pacc[NSUB][NT16];  // tile n of subtile st, register i <-> output channel 16 n + 4 g + i
 
@@ -318,8 +369,8 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
                     const float v = pacc[a][n][i] + (float)xf[0][st][ks][j];
                     xf[0][st][ks][j] = (T)(v + bq3.q[n][i]);
                 }
-            if (store && lds_px[0][st] >= 0) {
-                T* Oimg = O + (size_t)img * H * W * C;
+            if (store && lds_px[0][st] >= 0 && (!STACK || img * G + img_of[0][st] < B)) {
+                T* Oimg = O + (size_t)img * G * H * W * C;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const V8 v = xf[0][st][ks];
@@ -345,7 +396,8 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
         // package buffer s & 1.
         static_assert(MTIW == 1 && !ESPLIT && MTI == MTO && MTO < NW, "one tile per wave and a wave to spare");
         __syncthreads();                                   // zeroed images and flags
-        const int nimg = (B - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
+        const int NU = (B + G - 1) / G;                    // images, or groups of G stacked images
+        const int nimg = (NU - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
         const int NS = nimg * npk;
         // spin until `cond` holds for every lane (flags only ever grow)
         auto wait_flags = [&](auto cond) {
@@ -375,7 +427,7 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
             const bool has_nb = nb >= 0 && nb < MTO;
             const int nbc = has_nb ? nb : wave;
             int s = 0;
-            for (int img = blockIdx.y; img < B; img += gridDim.y) {
+            for (int img = blockIdx.y; img < NU; img += gridDim.y) {
                 load_x(img);
 #pragma unroll 1
                 for (int b = 0; b < nblk; ++b) {
@@ -497,12 +549,14 @@ static int rb_compute_units() {
     return cus;
 }
 
-template <typename T, int C, int CEXP, int H, int TR, int NW>
+template <typename T, int C, int CEXP, int H, int TR, int NW, int G = 1>
 static int launch_rblock_cfg(const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s) {
     constexpr int bands = H / TR;
-    constexpr int lds = rblock_lds_bytes<C, CEXP, H, TR>();
-    FRA_REQUIRE(nblk == 1 || TR == H, FRA_ERR_ARG, "rblock: %d blocks per launch need whole-image workgroups", nblk);
-    auto kern = rblock_kernel<T, C, CEXP, H, TR, NW>;
+    constexpr int lds = rblock_lds_bytes<C, CEXP, H, TR, NW, G>();
+    FRA_REQUIRE(nblk == 1 || (TR == H && rb_main_tiles<H, TR, G>() > NW / 2), FRA_ERR_ARG,
+                "rblock: %d blocks per launch need whole-image workgroups with a tile per wave", nblk);
+    static_assert(G == 1 || rb_flags<H, TR, NW, G>(), "stacked images run on the flag-synchronised loop");
+    auto kern = rblock_kernel<T, C, CEXP, H, TR, NW, G>;
     static std::atomic<uint64_t> lds_set;      // per instantiation: devices whose LDS limit is raised
     static std::atomic<int> slots_of[64];      // resident workgroups per band, per device (0 = not asked yet)
     int dev = 0;
@@ -513,17 +567,34 @@ static int launch_rblock_cfg(const void* x, const void* wp, int nblk, void* out,
         if (slots < 1) slots = 1;
         if (dev < 64) slots_of[dev].store(slots, std::memory_order_relaxed);
     }
-    // one workgroup per band and resident slot, each walking over its images in equal shares
-    const int per = (B + slots - 1) / slots;
-    const int groups = (B + per - 1) / per;
+    // one workgroup per band and resident slot, each walking over its images (groups of G images) in equal shares
+    const int units = (B + G - 1) / G;
+    const int per = (units + slots - 1) / slots;
+    const int groups = (units + per - 1) / per;
     hipLaunchKernelGGL(kern, dim3(bands, groups), dim3(NW * 64), lds, s, (const T*)x, (const char*)wp, (T*)out, B, nblk);
     FRA_HIP(hipGetLastError());
     return FRA_OK;
 }
 
+#ifndef RB_STACK2_PER_CU
+#define RB_STACK2_PER_CU 1   // pairs of stacked 7 x 7 images per compute unit up to which the two-image workgroups run
+#endif
 #ifndef RB_NW_WHOLE
 #define RB_NW_WHOLE 8      // waves of a whole-image workgroup (7 tiles of two rows; the eighth wave only stages)
 #endif
+// conv_5 (128 -> 256 -> 128 on 7 x 7), workgroup shape by batch size: 0 = one-row bands (7 workgroups per image, one
+// block per launch) while those fit the chip in one go; 2 = two stacked images per workgroup (four tile waves) while
+// a compute unit gets at most RB_STACK2_PER_CU such pairs; 4 = four stacked images (seven tile waves).  2 and 4 chain
+// blocks in one launch.  (A whole image per workgroup with two waves per tile, one block per launch, was measured:
+// 29 us for the two blocks at 37 to 256 images, what the two-image chain takes.)  FRA_RB_STACK=0|2|4 forces a shape
+// (measurements).
+static int rb_stack_choice(int B, int cus) {
+    static const int forced = [] { const char* e = getenv("FRA_RB_STACK"); return e ? atoi(e) : -1; }();
+    if (forced == 0 || forced == 2 || forced == 4) return forced;
+    if ((int64_t)B * 7 <= cus) return 0;
+    return B <= 2 * RB_STACK2_PER_CU * cus ? 2 : 4;
+}
+
 // conv_4 (128 -> 256 -> 128 on 14 x 14): bands of 2 rows (7 workgroups per image) while those fit the chip in
 // one go, bands of 7 rows (2 per image) while those do, whole images beyond
 template <typename T>
@@ -535,6 +606,13 @@ static int launch_rblock_t(int c, int cexp, int h, const void* x, const void* wp
         if ((int64_t)B * 2 <= cus) return launch_rblock_cfg<T, 128, 256, 14, 7, 8>(x, wp, 1, out, B, s);
         return launch_rblock_cfg<T, 128, 256, 14, 14, RB_NW_WHOLE>(x, wp, 1, out, B, s);
     }
+    if (c == 128 && cexp == 256 && h == 7) {
+        int g = rb_stack_choice(B, cus);
+        if (nblk > 1 && g < 2) g = 2;                      // several blocks per launch: only the stacked shapes chain
+        if (g == 0) return launch_rblock_cfg<T, 128, 256, 7, 1, 8>(x, wp, 1, out, B, s);
+        if (g == 2) return launch_rblock_cfg<T, 128, 256, 7, 7, 5, 2>(x, wp, nblk, out, B, s);
+        return launch_rblock_cfg<T, 128, 256, 7, 7, 8, 4>(x, wp, nblk, out, B, s);
+    }
     FRA_REQUIRE(false, FRA_ERR_ARG, "rblock: no kernel for c=%d cexp=%d h=%d", c, cexp, h);
     return FRA_ERR_ARG;
 }
@@ -544,8 +622,10 @@ bool rblock_chain_pays(int c, int cexp, int h, int B) {
     // per-block launches as soon as the two-row bands of a batch no longer fit the chip in one go
     // (FRA_RB_CHAIN_MIN=<batch> moves the limit, for measurements)
     static const int min_b = [] { const char* e = getenv("FRA_RB_CHAIN_MIN"); return e ? atoi(e) : 0; }();
-    if (min_b > 0) return c == 128 && cexp == 256 && h == 14 && B >= min_b;
-    return c == 128 && cexp == 256 && h == 14 && (int64_t)B * 7 > rb_compute_units();
+    if (c == 128 && cexp == 256 && h == 7) return rb_stack_choice(B, rb_compute_units()) >= 2;
+    const bool shape = c == 128 && cexp == 256 && h == 14;
+    if (min_b > 0) return shape && B >= min_b;
+    return shape && (int64_t)B * 7 > rb_compute_units();
 }
 
 int launch_rblock(int dt, int c, int cexp, int h, const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s) {

@@ -144,7 +144,7 @@ static void build_ops(mfn_handle* h, bool fused) {
             o.flops = 2.0 * (pin * cin * cexp + pout * cexp * 9 + pout * cexp * cout);
             o.bytes = (pin * cin + pout * cout) * es;    // the shortcut re-reads the input tile: no extra traffic
             o.wbytes = ((double)cin * cexp + 9.0 * cexp + (double)cexp * cout) * es;
-            if (res && stride == 1 && cin == 128 && hin == 14 && rblock_package_bytes(cin, cexp) > 0) {   // conv_4.*
+            if (res && stride == 1 && cin == 128 && (hin == 14 || hin == 7) && rblock_package_bytes(cin, cexp) > 0) {   // conv_4.*, conv_5.*
                 o.rblock = true;
                 o.chain_pos = chain_i;
                 o.chain_len = chain_n;
@@ -165,7 +165,9 @@ static void build_ops(mfn_handle* h, bool fused) {
     for (chain_i = 0; chain_i < 6; ++chain_i) block("conv_4.model." + std::to_string(chain_i), 128, 256, 128, 1, true, 14);
     chain_i = 0; chain_n = 1;
     block("conv_45", 128, 512, 128, 2, false, 14);
-    for (int i = 0; i < 2; ++i) block("conv_5.model." + std::to_string(i), 128, 256, 128, 1, true, 7);
+    chain_n = 2;
+    for (chain_i = 0; chain_i < 2; ++chain_i) block("conv_5.model." + std::to_string(chain_i), 128, 256, 128, 1, true, 7);
+    chain_i = 0; chain_n = 1;
     // face_model.py:88-92
     if (fused) {
         add(OP_TAIL, "conv_6_dw", cur, BUF_V, NO_RESID, 128, 512, 7, 1, 1, false);           // conv_6_sep + conv_6_dw

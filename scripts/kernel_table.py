@@ -31,6 +31,7 @@ names = {"block_kernel<_Float16, 64, 128, 64, 28, 1>": "`block_kernel` 64â†’128â
          "block_kernel<_Float16, 64, 256, 128, 28, 2>": "`block_kernel` 64â†’256â†’128 @28Â², s2 (conv_34, Ã—1)",
          "block_kernel<_Float16, 128, 512, 128, 14, 2>": "`block_kernel` 128â†’512â†’128 @14Â², s2 (conv_45, Ã—1)",
          "block_kernel<_Float16, 128, 256, 128, 7, 1>": "`block_kernel` 128â†’256â†’128 @7Â², s1 (conv_5, Ã—2)",
+         "rblock_kernel<_Float16, 128, 256, 7>": "`rblock_kernel` 128â†’256â†’128 @7Â², s1 (conv_5: two blocks, ONE launch, four stacked images per workgroup)",
          "linear_l2norm_kernel<_Float16, 16, 1>": "`linear_l2norm_kernel` + `l2norm_rows_kernel`",
          "tail_kernel<_Float16>": "`tail_kernel` (conv_6_sep + conv_6_dw)"}
 tb = tt = ts = 0.0

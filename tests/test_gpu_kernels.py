@@ -132,14 +132,16 @@ def _rblock_packages(lib, code, c, cexp, w1, b1, s1, w2, b2, s2, w3, b3):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
-@pytest.mark.parametrize("B", [2, 37, 129, 300])
-def test_rblock_chain(device, dt, B):
-    """Three residual blocks (128 -> 256 -> 128 on 14 x 14) back to back: one launch with the activation kept in
-    registers == three launches bit for bit, for every band configuration the batch size selects (2-row bands,
-    7-row bands, whole images), and both match the torch convs on 16-bit-rounded operands."""
+@pytest.mark.parametrize("H,B", [(14, 2), (14, 37), (14, 129), (14, 300), (7, 2), (7, 37), (7, 131), (7, 300), (7, 515), (7, 1030)])
+def test_rblock_chain(device, dt, H, B):
+    """Three residual blocks (128 -> 256 -> 128 on 14 x 14 or 7 x 7) back to back: one launch with the activation kept
+    in registers == three launches bit for bit, for every configuration the batch size selects (14 x 14: 2-row bands,
+    7-row bands, whole images; 7 x 7: one-row bands, workgroups of one image or of two or four stacked images, batches that are no
+    multiple of those), a small batch's images come out the same bits inside a large one, and all match the torch
+    convs on 16-bit-rounded operands."""
     tdt, code, rel = DT[dt]
     lib = _lib.load()
-    c, cexp, H, nblk = 128, 256, 14, 3
+    c, cexp, nblk = 128, 256, 3
     g = torch.Generator().manual_seed(5)
     x = torch.randn((B, c, H, H), generator=g).to(tdt).float()
     pks, y = [], x
@@ -169,9 +171,15 @@ def test_rblock_chain(device, dt, B):
     chained = xd.clone()
     _lib.check(lib.mfn_op_rblock(code, c, cexp, H, chained.data_ptr(), pk.data_ptr(), nblk, chained.data_ptr(), B,
                                  stream(device)), "rblock chain")
+    # the first images as a batch of their own (another configuration for the large batches)
+    nb = min(B, 33)
+    head = xd[:nb].clone()
+    _lib.check(lib.mfn_op_rblock(code, c, cexp, H, head.data_ptr(), pk.data_ptr(), nblk, head.data_ptr(), nb,
+                                 stream(device)), "rblock chain, small batch")
     torch.cuda.synchronize()
     assert torch.equal(cur, chained)
-    close(chained, ref, 6 * rel, f"rblock chain B={B}")
+    assert torch.equal(head, chained[:nb])
+    close(chained, ref, 6 * rel, f"rblock chain H={H} B={B}")
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
@@ -213,14 +221,16 @@ def test_fused_block(device, dt, cin, cexp, cout, H, stride, res, B, many):
     w3d, b3d = dev(_w3_image(w3[:, inv], cout).to(tdt)), dev(b3)
     Ho = H // stride
     out = torch.full((B, Ho, Ho, cout), float("nan"), dtype=tdt, device=device)
-    if (cin, cexp, H, stride) == (128, 256, 14, 1):
-        # this shape runs in the register-resident residual kernel, which takes its weights as packages
+    if (cin, cexp, stride) == (128, 256, 1) and H in (14, 7):
+        # these shapes run in the register-resident residual kernel, which takes its weights as packages
         pk = _rblock_packages(lib, code, cin, cexp, w1, b1, s1, w2, b2, s2, w3, b3).to(device)
         _lib.check(lib.mfn_op_rblock(code, cin, cexp, H, xd.data_ptr(), pk.data_ptr(), 1, out.data_ptr(), B, stream(device)),
                    "rblock")
         torch.cuda.synchronize()
         close(out, ref, 3 * rel, f"rblock {cin}->{cexp}->{cout} H={H}")
-        return
+        if H == 14:
+            return
+        out = torch.full((B, Ho, Ho, cout), float("nan"), dtype=tdt, device=device)   # the band kernel has this shape too
     _lib.check(lib.mfn_op_block(code, cin, cexp, cout, H, stride, int(res), xd.data_ptr(), w1d.data_ptr(),
                                 b1d.data_ptr(), s1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), s2d.data_ptr(),
                                 w3d.data_ptr(), b3d.data_ptr(), out.data_ptr(), B, stream(device)), "block")
