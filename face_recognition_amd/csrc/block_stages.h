@@ -145,7 +145,8 @@ template <typename T, int KS1, int CEXP, int PW1> struct ExpStage {
 // stored in that order when their slice is staged).
 // NQ: chunks of the slice this wave handles (4, or 2 = one chunk pair when two waves share a tile)
 // NSUB: 16-pixel subtiles this wave handles (2, or 1 when two waves share a tile: `tb` then points at the wave's subtile)
-template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ, int NSUB = 2> struct DwStage {
+// SEP: the second subtile is not a fixed distance from the first: it has tap bases of its own (tbr1, with ROWB == 0)
+template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ, int NSUB = 2, bool SEP = false> struct DwStage {
     typedef typename vec8<T>::type V8;
     typedef typename vec16<T>::type V16;
     V8 er[DW_RING][NSUB][2];       // ring: the two image units of this lane's tap, per subtile
@@ -158,6 +159,7 @@ template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ, in
     V8 bf[NSUB];                   // project B operand of the chunk pair, per subtile
     int tb;                        // LDS address of this lane's tap (0, min(g, 2)) in subtile 0; + p ROWB + 32 q (+ 16: second unit) (+ ST1: subtile 1)
     int tbr[DW_ROWS];              // (ROWB == 0: the window's rows are not a fixed distance apart) that address per window row p
+    int tbr1[DW_ROWS];             // (SEP) the same for subtile 1
     int w2l;                       // this lane's word of the 3x3 weight image: plane g & 1, position m; + p dw_wrow + 64 q
     int pb;                        // depthwise bias quad of channels 4g..; + 64 q; slopes CEXP*4 further
     int w3l;                       // this lane's project weight row 16 (g & 1) + m, unit g >> 1; + 32 n PW3 + 32 pair
@@ -179,7 +181,11 @@ template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ, in
         const int base = ROWB ? tb : tbr[p];
         LDS_READ16(er[ST % DW_RING][0][0], base, off);
         LDS_READ16(er[ST % DW_RING][0][1], base, off + 16);
-        if constexpr (NSUB == 2) {
+        if constexpr (NSUB == 2 && SEP) {
+            static_assert(!SEP || ROWB == 0, "separate subtile bases come per window row");
+            LDS_READ16(er[ST % DW_RING][1][0], tbr1[p], off);
+            LDS_READ16(er[ST % DW_RING][1][1], tbr1[p], off + 16);
+        } else if constexpr (NSUB == 2) {
             LDS_READ16(er[ST % DW_RING][1][0], base, ST1 + off);
             LDS_READ16(er[ST % DW_RING][1][1], base, ST1 + off + 16);
         }

@@ -1,20 +1,24 @@
-// Fused inverted-residual block as a ROW PIPELINE inside one workgroup, without workgroup-wide barriers
+// Fused inverted-residual block as a PIPELINE inside one workgroup, without workgroup-wide barriers
 // (reference: Residual / Depth_Wise.forward, face_model.py:55-75; stride 1, C -> CEXP -> C, + x).
 //
 // kernels_block.hip walks a band through barrier-separated stages (expand a slice | barrier | depthwise +
 // project | barrier ...): every wave does the same kind of work at the same time, and a quarter of the cycles go
-// to waiting at those barriers.  Here the waves of a workgroup have ROLES:
-//   * NP producer waves: wave p expands image rows p, p + NP, ... (all CEXP channels of the row, 32x32x16 MFMAs,
-//     PReLU) into a ring of NR rows in LDS and raises the row's flag;
-//   * NC consumer waves: wave c computes output rows c, c + NC, ...: waits for the flags of the three rows of
-//     the 3x3 window, runs the depthwise + project stage of block_stages.h on them (per-row tap bases, a row of
-//     zeros where the window leaves the image), adds bias and shortcut in registers and stores the row;
-//     then publishes its progress, which is what lets a producer overwrite the oldest ring row.
-// A wave only ever waits for the rows it needs, by polling a word in LDS; the only barrier is the one after the
+// to waiting at those barriers.  Here the waves of a workgroup have ROLES, and the unit that moves between them is a
+// TILE of 32 consecutive pixels in row-major order (a row of 28 would leave four of a tile's 32 lanes idle; pixels are
+// columns of every matrix product, so which pixels share a tile changes nothing about a value):
+//   * NP producer waves: wave p expands tiles p, p + NP, ... (all CEXP channels of the tile's pixels, 32x32x16 MFMAs,
+//     PReLU) into a ring of NR image rows in LDS and raises the tile's flag;
+//   * NC consumer waves: wave c computes output tiles c, c + NC, ...: the 3x3 windows of a tile's pixels reach 29
+//     pixels back and forth, i.e. into the two neighbouring tiles only, so it waits for the flags of tiles t - 1, t and
+//     t + 1, runs the depthwise + project stage of block_stages.h with per-lane tap bases (each of a lane's two pixels
+//     has its own three window rows; a row of zeros where the window leaves the image), adds bias and shortcut in
+//     registers and stores its pixels; then publishes its progress, which is what lets a producer overwrite the
+//     oldest ring rows.
+// A wave only ever waits for the tiles it needs, by polling a word in LDS; the only barrier is the one after the
 // set-up.  Both weight matrices of the block stay in LDS for the whole kernel (the ring is a few rows, not a band's
 // whole expanded image), so there is no weight pipeline either.  A workgroup owns whole images and walks over
-// images blockIdx.y, blockIdx.y + gridDim.y, ...; rows are numbered through (G = 28 k + y for the k-th image), and
-// the pipeline runs on across image boundaries.
+// images blockIdx.y, blockIdx.y + gridDim.y, ...; pixels are numbered through (P = 784 k + 28 y + x for the k-th
+// image, ring row P / 28), and the pipeline runs on across image boundaries.
 //
 // Per output value the arithmetic -- MFMA shapes, operand order, roundings, (acc + x) + b3 -- is block_kernel's,
 // so the two kernels give the same bits and the launcher may pick either by batch size.
@@ -24,16 +28,23 @@ namespace fra {
 
 template <int CIN, int CEXP, int COUT, int H, int NR> struct PbLds {
     static constexpr int SLOT = CEXP * 2 + 16;             // bytes per pixel slot: all expanded channels + one unit of padding
-    static constexpr int PITCH = H + 2;                    // pixel slots per row (zero border each side)
+#ifndef PB_BORDER
+#define PB_BORDER 1
+#endif
+    // pixel slots per row: a zero border slot, then the pixels; the next row's border slot is this row's right border
+    // (the zero row follows the ring's last row).  Rows one slot apart in bank terms keep the 16 lanes of a tap read
+    // that straddles a row end on almost distinct banks.
+    static constexpr int PITCH = H + PB_BORDER;
     static constexpr int ROWB = PITCH * SLOT;
-    static constexpr int OFF_ZERO = NR * ROWB;             // a row of zeros (+ slack: lanes past the row end read on)
+    static constexpr int OFF_ZERO = NR * ROWB;             // four slots of zeros: a window row outside the image (every lane reads the same three taps), and the right border of the ring's last row
     static constexpr int PW1 = CIN * 2 + 16, PW3 = 80, NCH = CEXP / 64;
     static constexpr int W1_BYTES = 64 * PW1, W3_BYTES = 2 * COUT * PW3, WB_BYTES = W1_BYTES + W3_BYTES;
-    static constexpr int OFF_WB = (OFF_ZERO + ROWB + 8 * SLOT + 15) / 16 * 16;
+    static constexpr int OFF_WB = (OFF_ZERO + 4 * SLOT + 15) / 16 * 16;
     static constexpr int OFF_B1 = OFF_WB + NCH * WB_BYTES, OFF_S1 = OFF_B1 + CEXP * 4, OFF_B2 = OFF_S1 + CEXP * 4,
                          OFF_S2 = OFF_B2 + CEXP * 4, OFF_W2 = OFF_S2 + CEXP * 4;
-    static constexpr int OFF_FLAGS = OFF_W2 + dw_wimage_bytes(CEXP);   // ready[NR] | progress[8]
-    static constexpr int BYTES = OFF_FLAGS + (NR + 8) * 4;
+    static constexpr int NTF = 16;                         // tile flags (a ring; a word only ever grows, by NTF per use)
+    static constexpr int OFF_FLAGS = OFF_W2 + dw_wimage_bytes(CEXP);   // ready[NTF] | progress[8]
+    static constexpr int BYTES = OFF_FLAGS + (NTF + 8) * 4;
 };
 
 // -DPB_STAMPS: per wave, the shader-clock cycles spent in each part of its loop, summed over the kernel, go to a
@@ -63,21 +74,23 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
     typedef typename vec8<T>::type V8;
     typedef typename vec4<T>::type V4;
     typedef PbLds<CIN, CEXP, COUT, H, NR> L;
-    constexpr int NW = NP + NC, NT = NW * 64, W = H;
+    constexpr int NW = NP + NC, NT = NW * 64, W = H, HW = H * W, NTF = L::NTF;
     constexpr int KS1 = CIN / 16, NT16 = COUT / 16, NCH = L::NCH, CH1 = CIN / 8;
     constexpr int SLOT = L::SLOT, ROWB = L::ROWB, PW1 = L::PW1, PW3 = L::PW3;
     constexpr int NI1 = L::W1_BYTES / 1024, NI3 = L::W3_BYTES / 1024;
     static_assert(L::W1_BYTES % 1024 == 0 && L::W3_BYTES % 1024 == 0, "weight images are whole DMA pieces");
-    static_assert(NR >= (NP > 0 ? NC + 3 : NW + 3), "ring rows: the windows of all consumers and one row being written");
-    static_assert(W <= 28 && W > 16, "a row is one 32-lane tile: two 16-pixel subtiles");
+    // the lowest tile not yet expanded (at most one past the lowest tile not yet computed, t) may always be written:
+    // its last row is at most (32 t + 63) / W, and the rows NR below that are read for tiles before t only
+    static_assert(NP > 0 && W * (NR - 2) > 62, "ring rows");
+    static_assert(W + 1 <= 32, "a tile's windows (W + 1 pixels back and forth) stay inside the two neighbouring tiles");
     static_assert(CIN == COUT && CEXP % 64 == 0 && NC <= 8, "shape");
     static_assert(L::BYTES <= 160 * 1024, "LDS budget");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    volatile int* ready = reinterpret_cast<volatile int*>(lds + L::OFF_FLAGS);   // ready[G % NR] = G + 1 once row G is in the ring
-    volatile int* progress = ready + NR;                   // progress[c]: last output row consumer c has finished reading for
+    volatile int* ready = reinterpret_cast<volatile int*>(lds + L::OFF_FLAGS);   // ready[t % NTF] = t + 1 once tile t is in the ring
+    volatile int* progress = ready + NTF;                  // progress[c]: last tile consumer c has finished reading for
 
     // ---- set-up: weights of every slice by LDS-DMA, parameters, zeroed ring, flags ---------------------------
 #pragma unroll
@@ -117,8 +130,8 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
     }
     // ring + zero row + slack: border slots stay zero for ever, everything a lane may read is a finite value
     for (int i = tid; i < L::OFF_WB / 16; i += NT) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tid < NR) ready[tid] = 0;
-    if (tid < 8) progress[tid] = tid < (NP > 0 ? NC : NW) ? tid - (NP > 0 ? NC : NW) : 0x3fffffff;
+    if (tid < NTF) ready[tid] = 0;
+    if (tid < 8) progress[tid] = tid < NC ? tid - NC : 0x3fffffff;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -127,28 +140,36 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
     PB_T(t_begin);
 #endif
     const int nimg = (B - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int NG = nimg * H;                               // rows this workgroup handles, numbered through
+    const int NPX = nimg * HW;                             // pixels this workgroup handles, numbered through
+    const int NTL = (NPX + 31) / 32;                       // ... in tiles of 32 (the last one may be part empty)
+    // pixel P -> element offset of its first channel in X / O (CIN == COUT)
+    auto pixel_offset = [&](int P) -> size_t {
+        const int k = P / HW;
+        return ((size_t)((int)blockIdx.y + k * (int)gridDim.y) * HW + (size_t)(P - k * HW)) * CIN;
+    };
 
-    // ================= produce: expand row G into ring slot G % NR =================
-    constexpr int NCONS = NP > 0 ? NC : NW;                // waves that consume rows (their progress words)
+    // ================= produce: expand tile t into the ring rows of its pixels =================
     const int r = lane & 31, h = lane >> 5;
-    const int px = r < W ? r : W - 1;                      // lanes past the row end load a valid pixel and write nothing
-    const int wr = r < W ? (r + 1) * SLOT + 16 * h : -1;
-    V8 xf[KS1], xn[KS1];                                   // input fragments of the row to expand, and of the one after it
-    auto load_row = [&](V8 (&dst)[KS1], int G) {
-        const int k = G / H, y = G - k * H;
-        const T* ptr = X + ((size_t)((int)blockIdx.y + k * (int)gridDim.y) * H * W + (size_t)y * W + px) * CIN + 8 * h;
+    V8 xf[KS1], xn[KS1];                                   // input fragments of the tile to expand, and of the one after it
+    auto load_tile = [&](V8 (&dst)[KS1], int t) {
+        const int P = cmin_rt(32 * t + r, NPX - 1);        // lanes past the last pixel load a valid one and write nothing
+        const T* ptr = X + pixel_offset(P) + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) dst[ks] = *reinterpret_cast<const V8*>(ptr + 16 * ks);
     };
     typedef ExpStage<T, KS1, CEXP, PW1> Ex;
-    // xf holds row G's fragments; Gnext (if < NG) is the row this wave expands next: requested now, moved over at the end
-    auto produce = [&](int G, int Gnext) {
-        if (Gnext < NG) load_row(xn, Gnext);
+    // xf holds tile t's fragments; tnext (if < NTL) is the tile this wave expands next: requested now, moved over at the end
+    auto produce = [&](int t, int tnext) {
+        if (tnext < NTL) load_tile(xn, tnext);
         PB_T(t0);
-        if (G >= NR) {
-            // slot G % NR holds row G - NR, read for output rows up to G - NR + 1: every consumer must be past them
-            const int need = G - NR - NCONS + 2;
+        const int P = 32 * t + r;
+        const int G = P / W, x = P - G * W;                // ring row (numbered through) and column of this lane's pixel
+        const int wr = P < NPX ? (G % NR) * ROWB + (x + 1) * SLOT + 16 * h : -1;
+        const int glast = (32 * t + 31) / W;               // last row the tile writes
+        if (glast >= NR) {
+            // row glast - NR is overwritten: it was read for output rows up to glast - NR + 1, whose last pixel lies in
+            // tile `last`; consumer c is past it once progress[c] >= last - NC + 1 (its tiles are NC apart)
+            const int need = (W * (glast - NR + 2) - 1) / 32 - NC + 1;
             for (int spin = 0; spin < PB_SPIN_LIMIT; ++spin) {
                 const int v = progress[lane & 7];
                 if (__builtin_amdgcn_ballot_w64(v < need) == 0) break;
@@ -158,7 +179,6 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
         asm volatile("" ::: "memory");
         PB_T(t1);
         PB_ACC(0, t0, t1);
-        char* rowl = lds + (G % NR) * ROWB;
         static_for<NCH>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             static_for<2>([&](auto ntc) {
@@ -182,47 +202,61 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
                                 o[4 * a + i] = (T)fmaf(neg_part(v), ex.sl[q][i], v);   // PReLU: sl = slope - 1
                             }
                         }
-                        *reinterpret_cast<V8*>(rowl + wr + 128 * c + (2 * nt + s2) * 32) = o;
+                        *reinterpret_cast<V8*>(lds + wr + 128 * c + (2 * nt + s2) * 32) = o;
                     }
                 }
             });
         });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the row is in LDS before its flag goes up
-        if (lane == 0) ready[G % NR] = G + 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the tile is in LDS before its flag goes up
+        if (lane == 0) ready[t % NTF] = t + 1;
         PB_T(t2);
         PB_ACC(1, t1, t2);
-        if (Gnext < NG) {
+        if (tnext < NTL) {
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) xf[ks] = xn[ks];
         }
     };
 
-    // ================= consume: output row G from ring rows G - 1, G, G + 1 =================
+    // ================= consume: output tile t from the ring rows around its pixels =================
     const int m16 = lane & 15, g4 = lane >> 4;
-    constexpr int ST1 = 16 * SLOT;
-    const int lpart = (m16 + (g4 < 2 ? g4 : 2)) * SLOT;    // this lane's tap (., min(g, 2)) of subtile 0 inside a row
-    const bool ok1 = m16 + 16 < W;                         // subtile 1: columns 16 ..
     f32x4 b3q[NT16];
 #pragma unroll
     for (int n = 0; n < NT16; ++n) b3q[n] = *reinterpret_cast<const f32x4*>(b3 + 16 * n + 4 * g4);
-    auto consume = [&](int G, int cw) {                    // cw: this wave's progress word
-        const int k = G / H, y = G - k * H;
-        const size_t pix = ((size_t)((int)blockIdx.y + k * (int)gridDim.y) * H + y) * W;
-        const T* xs = X + (pix + m16) * CIN + 4 * g4;
-        T* os = O + (pix + m16) * COUT + 4 * g4;
-        // shortcut values: channels 16 n + 4 g .. of this lane's pixel, per subtile
+    auto consume = [&](int t, int cw) {                    // cw: this wave's progress word
+        // this lane's pixel of each 16-pixel subtile: global offsets, validity, tap bases of the three window rows
+        size_t goff[2];
+        bool ok[2];
+        int rowb[2][3];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int P0 = 32 * t + 16 * st + m16;
+            ok[st] = P0 < NPX;
+            const int P = ok[st] ? P0 : NPX - 1;           // lanes past the last pixel compute it again and store nothing
+            goff[st] = pixel_offset(P) + 4 * g4;
+            const int G = P / W, x = P - G * W, y = G % H;
+            const int gpart = (g4 < 2 ? g4 : 2) * SLOT;    // tap (., min(g, 2)) ...
+            const int lpart = x * SLOT + gpart;            // ... of this pixel inside a ring row
+            const int slot0 = (G + NR - 1) % NR;           // ring slot of the row above
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int yy = y - 1 + p;
+                int slot = slot0 + p;
+                slot = slot >= NR ? slot - NR : slot;
+                rowb[st][p] = yy >= 0 && yy < H ? slot * ROWB + lpart : L::OFF_ZERO + gpart;
+            }
+        }
+        // shortcut values: channels 16 n + 4 g .. of this lane's pixels
         V4 rr[2][NT16];
 #pragma unroll
-        for (int n = 0; n < NT16; ++n) {
-            rr[0][n] = *reinterpret_cast<const V4*>(xs + 16 * n);
-            if (ok1) rr[1][n] = *reinterpret_cast<const V4*>(xs + 16 * CIN + 16 * n);
-        }
-        // wait for the window's rows (those inside the image)
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int n = 0; n < NT16; ++n) rr[st][n] = *reinterpret_cast<const V4*>(X + goff[st] + 16 * n);
+        // wait for the tiles the windows reach into
         PB_T(t0);
         {
-            const int d = (lane % 3) - 1, yy = y + d;
-            const bool inside = yy >= 0 && yy < H;
-            const int idx = (G + d + NR) % NR, want = G + d + 1;
+            const int tt = t + (lane % 3) - 1;
+            const bool inside = tt >= 0 && tt < NTL;
+            const int idx = (tt + NTF) % NTF, want = tt + 1;
             for (int spin = 0; spin < PB_SPIN_LIMIT; ++spin) {
                 const int v = ready[idx];
                 if (__builtin_amdgcn_ballot_w64(inside && v < want) == 0) break;
@@ -232,12 +266,6 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
         asm volatile("" ::: "memory");
         PB_T(t1);
         PB_ACC(3, t0, t1);
-        int rowb[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const int yy = y - 1 + p;
-            rowb[p] = (yy >= 0 && yy < H ? ((G - 1 + p + NR) % NR) * ROWB : L::OFF_ZERO) + lpart;
-        }
         f32x4 pacc[2][NT16];
 #pragma unroll
         for (int st = 0; st < 2; ++st)
@@ -245,10 +273,13 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
             for (int n = 0; n < NT16; ++n) pacc[st][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         static_for<NCH>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
-            DwStage<T, CEXP, NT16, PW3, ST1, 0, 4, 2> dw;
+            DwStage<T, CEXP, NT16, PW3, 0, 0, 4, 2, true> dw;
             dw.set_lane(m16, g4);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) dw.tbr[p] = rowb[p] + 128 * c;
+            for (int p = 0; p < 3; ++p) {
+                dw.tbr[p] = rowb[0][p] + 128 * c;
+                dw.tbr1[p] = rowb[1][p] + 128 * c;
+            }
             dw.w2l = L::OFF_W2 + (g4 & 1) * dw_wplane(CEXP) + (64 * c + m16) * 4;
             dw.pb = L::OFF_B2 + 256 * c + 16 * g4;
             dw.w3l = L::OFF_WB + c * L::WB_BYTES + L::W1_BYTES + (16 * (g4 & 1) + m16) * PW3 + 16 * (g4 >> 1);
@@ -256,57 +287,31 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
             dw.run(pacc);
         });
         asm volatile("" ::: "memory");
-        if (lane == 0) progress[cw] = G;                   // every read of the window has returned
+        if (lane == 0) progress[cw] = t;                   // every read of the windows has returned
         PB_T(t2);
         PB_ACC(4, t1, t2);
         // epilogue in registers: (acc + x) + b3, channel for channel what the lane holds
 #pragma unroll
-        for (int n = 0; n < NT16; ++n) {
-            V4 o;
+        for (int st = 0; st < 2; ++st)
+            if (ok[st]) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = (T)((pacc[0][n][i] + (float)rr[0][n][i]) + b3q[n][i]);
-            *reinterpret_cast<V4*>(os + 16 * n) = o;
-        }
-        if (ok1) {
+                for (int n = 0; n < NT16; ++n) {
+                    V4 o;
 #pragma unroll
-            for (int n = 0; n < NT16; ++n) {
-                V4 o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (T)((pacc[1][n][i] + (float)rr[1][n][i]) + b3q[n][i]);
-                *reinterpret_cast<V4*>(os + 16 * COUT + 16 * n) = o;
+                    for (int i = 0; i < 4; ++i) o[i] = (T)((pacc[st][n][i] + (float)rr[st][n][i]) + b3q[n][i]);
+                    *reinterpret_cast<V4*>(O + goff[st] + 16 * n) = o;
+                }
             }
-        }
         PB_T(t3);
         PB_ACC(5, t2, t3);
     };
 
-    if constexpr (NP > 0) {
-        // fixed roles: waves 0 .. NP-1 produce rows p, p + NP, ..., the others consume rows c, c + NC, ...
-        if (wave < NP) {
-            if (wave < NG) load_row(xf, wave);
-            for (int G = wave; G < NG; G += NP) produce(G, G + NP);
-        } else {
-            for (int G = wave - NP; G < NG; G += NC) consume(G, wave - NP);
-        }
+    // fixed roles: waves 0 .. NP-1 produce tiles p, p + NP, ..., the others consume tiles c, c + NC, ...
+    if (wave < NP) {
+        if (wave < NTL) load_tile(xf, wave);
+        for (int t = wave; t < NTL; t += NP) produce(t, t + NP);
     } else {
-        // every wave alternates: in round i it expands row NW i + w and computes output row NW i + w - 2 (the rows it
-        // needs, up to NW i + w - 1, come from the same round's earlier half).  The lower half of the waves expands first
-        // and computes second, the upper half the other way round (computing the previous round's row first), so the
-        // two waves of a SIMD (w and w + NW / 2) do different kinds of work at any time.
-        const int ph = wave >= NW / 2 ? 1 : 0;
-        const int cw = (wave + NW - 2) % NW;               // rows NW i + w - 2 are the rows cw, cw + NW, ...
-        if (wave < NG) load_row(xf, wave);
-        const int rounds = (NG + NW - 1) / NW + 2;
-        for (int t = 0; t < 2 * rounds; ++t) {
-            const int i = t >> 1;
-            if (((t + ph) & 1) == 0) {
-                const int G = NW * i + wave;
-                if (G < NG) produce(G, G + NW);
-            } else {
-                const int G = NW * (i - ph) + wave - 2;
-                if (G >= 0 && G < NG) consume(G, cw);
-            }
-        }
+        for (int t = wave - NP; t < NTL; t += NC) consume(t, wave - NP);
     }
 #ifdef PB_STAMPS
     PB_T(t_end);
@@ -321,7 +326,7 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
 #define PB_NP 3
 #endif
 #ifndef PB_NR
-#define PB_NR 10
+#define PB_NR 11
 #endif
 static int pb_compute_units() {
     static std::atomic<int> cus_of[64];        // compute units per device (0 = not asked yet)
@@ -335,7 +340,7 @@ static int pb_compute_units() {
 
 template <typename T, int CIN, int CEXP, int COUT, int H>
 static int launch_pblock_cfg(const BlockParams& p, const void* x, void* out, int B, hipStream_t s) {
-    constexpr int NP = PB_NP, NC = 8 - NP, NR = PB_NR;    // NP == 0: every wave expands and computes in turn
+    constexpr int NP = PB_NP, NC = 8 - NP, NR = PB_NR;
     constexpr int lds = PbLds<CIN, CEXP, COUT, H, NR>::BYTES;
     auto kern = pblock_kernel<T, CIN, CEXP, COUT, H, NP, NC, NR>;
     static std::atomic<uint64_t> lds_set;      // per instantiation: devices whose LDS limit is raised
