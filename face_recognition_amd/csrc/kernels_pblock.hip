@@ -355,15 +355,17 @@ static int launch_pblock_cfg(const BlockParams& p, const void* x, void* out, int
     return FRA_OK;
 }
 
-// A pipeline workgroup owns whole images: k = ceil(B / CUs) images one after the other, about 9 + 20.6 k microseconds
-// measured on 256 compute units, against 7 + 0.0906 B for the band kernels, whose bands fill the chip at any batch.  The
-// pipeline wins where the batch is a little under a multiple of the compute-unit count (250-256, 477-512, 704-768,
-// 931-1024 images, ...).
+// A pipeline workgroup owns whole images, k = ceil(B / CUs) of them one after the other: about 9 + 18.6 k microseconds
+// per launch, measured on 256 compute units.  The band kernels go over the chip in rounds of band-images: about
+// 9.25 + 11.06 ceil(2 B / CUs) microseconds with 14-row bands, 9.25 + 5.82 ceil(4 B / CUs) with 7-row bands, whichever
+// is less.  The pipeline wins where a batch leaves the bands' last round part empty and above some 640 images (193-256,
+// 385-512, 641 images and more on 256 compute units).
 bool pblock_pays(const BlockParams& p, int B) {
     if (!pblock_has(p)) return false;
-    const int cus = pb_compute_units();
-    const int64_t k = (B + cus - 1) / cus;
-    return (int64_t)B * 256 > (227 * k + 22) * cus;
+    const int64_t cus = pb_compute_units();
+    const int64_t k = (B + cus - 1) / cus, r14 = (2 * (int64_t)B + cus - 1) / cus, r7 = (4 * (int64_t)B + cus - 1) / cus;
+    const int64_t bands = 925 + (1106 * r14 < 582 * r7 ? 1106 * r14 : 582 * r7);   // hundredths of a microsecond
+    return 900 + 1860 * k < bands;
 }
 
 bool pblock_has(const BlockParams& p) {

@@ -126,16 +126,19 @@ def test_chained_and_per_block_launches_agree_bit_for_bit(hip_model, device):
 
 
 def test_row_pipeline_kernel_matches_band_kernels(device, hip_model, state_dict_np):
-    """conv_3 runs as a row pipeline inside a workgroup (producer / consumer waves, flags in LDS, no workgroup-wide
-    barriers) where a batch is just under a multiple of the compute-unit count, as band kernels elsewhere; both give
-    the same bits.  512 crops: pipeline, two images per workgroup; 256: pipeline, one image; 300 and 7: bands.  The
-    same with bf16 activations."""
+    """conv_3 runs as a pipeline inside a workgroup (producer / consumer waves hand tiles of 32 consecutive pixels on
+    through LDS, flags instead of workgroup-wide barriers) where the band kernels' last round over the chip would be
+    part empty, as band kernels elsewhere; both give the same bits.  512 crops: pipeline, two images per workgroup
+    (49 whole tiles); 256: pipeline, one image (its last tile half empty); 300 and 7: bands.  The same with bf16
+    activations."""
     B = 512
     x = torch.from_numpy(synthetic.make_crops(64, 23)).to(device).repeat(8, 1, 1, 1).contiguous()
     x += torch.linspace(-0.25, 0.25, B, device=device).view(B, 1, 1, 1)
     mb = MobileFaceNet(512, act_dtype="bf16")
     mb.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state_dict_np.items()})
     mb = mb.to(device).eval()
+    if torch.cuda.get_device_properties(device).multi_processor_count == 256:
+        assert [2 in hip_model.op_variants(b) for b in (512, 256, 300, 7)] == [True, True, False, False]
     for model in (hip_model, mb):
         full = model(x).cpu()
         assert torch.isfinite(full).all()
