@@ -632,6 +632,7 @@ int launch_rblock(int dt, int c, int cexp, int h, const void* x, const void* wp,
     FRA_REQUIRE(x && wp && out, FRA_ERR_ARG, "rblock: null pointer");
     FRA_REQUIRE(B > 0 && B <= 65535, FRA_ERR_ARG, "rblock: batch %d not in [1,65535]", B);
     FRA_REQUIRE(nblk >= 1 && nblk <= 64, FRA_ERR_ARG, "rblock: %d blocks", nblk);
+    FRA_REQUIRE(nblk > 1 || x != out, FRA_ERR_ARG, "rblock: a single block cannot run in place (bands read their neighbours' rows)");
     FRA_REQUIRE((((uintptr_t)wp) & 15) == 0, FRA_ERR_ARG, "rblock: packages must be 16-byte aligned");
     if (dt == ACT_F16) return launch_rblock_t<f16>(c, cexp, h, x, wp, nblk, out, B, s);
     if (dt == ACT_BF16) return launch_rblock_t<bf16>(c, cexp, h, x, wp, nblk, out, B, s);

@@ -71,9 +71,9 @@ int mfn_set_batch_chunk(mfn_handle* h, int images);
  * as one kernel; 0: one kernel per conv.  Changes mfn_op_count / mfn_op_info / mfn_debug_prefix. */
 int mfn_set_fused(mfn_handle* h, int fused);
 
-/* chain != 0 (the default): a run of identical residual blocks (conv_4.model.0-5, face_model.py:85) goes out as
- * ONE launch that keeps the activation in registers between blocks, for batches where whole-image workgroups
- * fill the chip; 0: one launch per block.  Same results bit for bit either way. */
+/* chain != 0 (the default): a run of identical residual blocks (conv_4.model.0-5 and conv_5.model.0-1,
+ * face_model.py:85-87) goes out as ONE launch that keeps the activation in registers between blocks, for batches
+ * where whole-image workgroups fill the chip; 0: one launch per block.  Same results bit for bit either way. */
 int mfn_set_chain(mfn_handle* h, int chain);
 /* first_op[i] (host, n_ops >= mfn_op_count entries) = the op whose launch covers op i in a batch of B images:
  * i itself, or the first block of the chain i runs in.  mfn_forward_timed books a chain's time on that op. */
@@ -101,7 +101,7 @@ int mfn_forward_timed(mfn_handle* h, const float* x_nchw, int B, float* out, voi
 int mfn_op_count(const mfn_handle* h);
 /* Which device kernel runs op `op` in a batch of B images (for benchmark labels; no counterpart in the reference):
  * 0 = the kernel of its kind (block_kernel for a fused block), 1 = rblock_kernel (residual blocks whose activation stays in
- * registers), 2 = pblock_kernel (the block as a row pipeline inside a workgroup).  Negative: an error code. */
+ * registers), 2 = pblock_kernel (the block as a pipeline of pixel tiles inside a workgroup).  Negative: an error code. */
 int mfn_op_variant(const mfn_handle* h, int op, int B);
 /* kind: 0 stem, 1 depthwise 3x3, 2 pointwise, 3 gdconv 7x7, 4 linear+l2norm, 5 fused block, 6 fused stem + first depthwise,
  * 7 fused tail (conv_6_sep + conv_6_dw).  flops / bytes are the
@@ -144,7 +144,9 @@ int mfn_op_block(int dtype, int cin, int cexp, int cout, int h, int stride, int 
  * weights in natural order: w1 [cexp][c], w2 [cexp][9] (tap = 3 ky + kx), w3 [c][cexp], biases, PReLU slopes
  * s1 / s2 [cexp]; out must hold mfn_rblock_package_bytes(c, cexp) bytes (0 = unsupported widths).
  * mfn_op_rblock runs nblk blocks whose packages lie back to back at `packages` (dev) on x -> out, both
- * T NHWC [B][h][h][c]; out may be x.  nblk > 1 keeps the activation in registers between blocks. */
+ * T NHWC [B][h][h][c] (h = 14 or 7).  nblk > 1 keeps the activation in registers between blocks, and out may then
+ * be x (a workgroup owns whole images); with nblk == 1 small batches run bands that read their neighbours' rows, so
+ * out must not be x. */
 int64_t mfn_rblock_package_bytes(int c, int cexp);
 int mfn_pack_rblock(int dtype, int c, int cexp, const float* w1, const float* b1, const float* s1, const float* w2,
                     const float* b2, const float* s2, const float* w3, const float* b3, void* packages_host);

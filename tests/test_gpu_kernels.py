@@ -375,3 +375,9 @@ def test_bad_arguments_report_errors(device):
                          96, 64, None) != 0
     assert lib.mfn_op_dw3x3(_lib.FRA_F16, out.data_ptr(), out.data_ptr(), out.data_ptr(), None, out.data_ptr(), 1, 10,
                             10, 64, 1, None) != 0
+    # one residual block in place: the bands of a small batch would read rows their neighbours have already replaced
+    big = torch.zeros(4096, dtype=torch.float16, device=device)
+    assert lib.mfn_op_rblock(_lib.FRA_F16, 128, 256, 7, big.data_ptr(), big.data_ptr(), 1, big.data_ptr(), 1, None) != 0
+    assert b"in place" in lib.fra_last_error()
+    assert lib.mfn_op_rblock(_lib.FRA_F16, 128, 256, 28, big.data_ptr(), big.data_ptr(), 2, big.data_ptr(), 1, None) != 0
+    assert b"no kernel" in lib.fra_last_error()
