@@ -335,7 +335,8 @@ def verification_timing(dev):
 
 def verification_12k(net, dev, pairs=12000, batch=256):
     """BASELINE configs[1], second half: 12k synthetic verification pairs through getFeature (flip-TTA: four
-    crop sets per batch, one forward for all four) and the 10-fold protocol on the device.  Same-pairs are two
+    crop sets per loader batch; getFeature runs consecutive loader batches of up to 1024 crops together as one
+    forward -- rows do not depend on the batch they are computed in) and the 10-fold protocol on the device.  Same-pairs are two
     noisy copies of one template, different-pairs two templates; crops are resident in HBM, as `value`'s are."""
     from face_recognition_amd import Evaluation
     ds = synthetic.PairSet(pairs)
@@ -358,7 +359,8 @@ def verification_12k(net, dev, pairs=12000, batch=256):
     t1_ = time.perf_counter()
     accs, thr = Evaluation.evaluation_10_fold(fl, fr, ds, "cos_distance")
     t2_ = time.perf_counter()
-    return {"pairs": pairs, "crops_embedded": 4 * pairs, "embed_s": round(t1_ - t0, 4),
+    return {"pairs": pairs, "loader_batch": batch, "crops_per_forward": max(4 * batch, 1024 // (4 * batch) * 4 * batch),
+            "crops_embedded": 4 * pairs, "embed_s": round(t1_ - t0, 4),
             "faces_per_s": round(4 * pairs / (t1_ - t0), 1), "protocol_10fold_ms": round((t2_ - t1_) * 1e3, 1),
             "accuracy": round(float(np.mean(accs)) * 100, 3), "threshold": round(float(np.mean(thr)), 4)}
 

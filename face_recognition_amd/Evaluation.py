@@ -62,27 +62,53 @@ def getThreshold(scores, flags, thrNum, method):
     return np.mean(thresholds[max_index])
 
 
-def getFeature(net, dataloader, device, flip=True, keep_on_device=False):
+def getFeature(net, dataloader, device, flip=True, keep_on_device=False, group_crops=None):
     """Evaluation.py:36-66.  ``dataloader`` yields lists ``[L, flip(L), R, flip(R)]`` of f32
     [b,3,112,112]; returns CPU f32 tensors (featureLs, featureRs) in loader order.
     ``keep_on_device=True`` (not in the reference) leaves them on the HIP device for
-    ``evaluation_10_fold``'s device path."""
+    ``evaluation_10_fold``'s device path.
+
+    ``group_crops`` (not in the reference): consecutive loader batches go through ONE forward as long as
+    they hold at most that many crops together (the reference harness's batch size 50 is 200 crops per
+    forward, a quarter of what fills the chip).  A row of the output does not depend on the batch it was
+    computed in -- bit for bit, for a network that says so (``net.batch_invariant``) -- so the features are
+    the ones a forward per loader batch gives.  Default: 1024 for such a network, else 0 = one forward per
+    loader batch, as the reference does."""
+    if group_crops is None:
+        group_crops = 1024 if getattr(net, "batch_invariant", False) else 0
     featureLs, featureRs = [], []
+    pending, pending_crops = [], 0
+
+    def flush():
+        flat = [d for det in pending for d in det]
+        with torch.no_grad():
+            res = torch.split(net(torch.cat(flat, 0)), [d.size(0) for d in flat], 0)   # one launch sequence for all of them
+            at = 0
+            for det in pending:
+                r = res[at:at + len(det)]
+                at += len(det)
+                if flip:
+                    featureLs.append(tta_combine(r[0], r[1]))
+                    featureRs.append(tta_combine(r[2], r[3]))
+                else:
+                    featureLs.append(r[0])
+                    featureRs.append(r[2])
+        pending.clear()
+
     for det in dataloader:
         det = [d.to(device, non_blocking=True) for d in det]
-        sizes = [d.size(0) for d in det]
-        with torch.no_grad():
-            res = torch.split(net(torch.cat(det, 0)), sizes, 0)   # one launch sequence for all four
-            if flip:
-                featureL = tta_combine(res[0], res[1])
-                featureR = tta_combine(res[2], res[3])
-            else:
-                featureL, featureR = res[0], res[2]
-        featureLs.append(featureL if keep_on_device else featureL.cpu())
-        featureRs.append(featureR if keep_on_device else featureR.cpu())
+        n = sum(d.size(0) for d in det)
+        if pending and pending_crops + n > group_crops:
+            flush()
+            pending_crops = 0
+        pending.append(det)
+        pending_crops += n
+    if pending:
+        flush()
     if not featureLs:
         return None, None
-    return torch.cat(featureLs, 0), torch.cat(featureRs, 0)
+    featureL, featureR = torch.cat(featureLs, 0), torch.cat(featureRs, 0)
+    return (featureL, featureR) if keep_on_device else (featureL.cpu(), featureR.cpu())
 
 
 def evaluation_10_fold(featureL, featureR, dataset, method="l2_distance"):

@@ -82,6 +82,10 @@ class MobileFaceNet(nn.Module):
     """MobileFaceNet(embedding_size); ``forward(x)``: f32 [B,3,112,112] (BGR, [-1,1]) on the HIP
     device -> new f32 [B,embedding_size] tensor with unit-norm rows."""
 
+    # a face's embedding is the same bits whatever batch it is computed in (every kernel configuration a batch size
+    # selects runs the same arithmetic per output value): callers may regroup batches freely (Evaluation.getFeature)
+    batch_invariant = True
+
     def __init__(self, embedding_size: int = 512, act_dtype: str = "f16"):
         super().__init__()
         self.embedding_size = int(embedding_size)

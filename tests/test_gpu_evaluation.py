@@ -43,6 +43,11 @@ def test_get_feature_and_10fold_vs_oracle(hip_model, device, state_dict_np):
     fl2, _ = Evaluation.getFeature(hip_model, _loader(left[:20], right[:20], 7), device, flip=False)
     want = mobilefacenet_ref.forward(state_dict_np, torch.from_numpy(left[:20])).numpy()
     assert cosine_rows(fl2.numpy(), want).min() >= 0.9999
+    # getFeature groups loader batches into forwards of up to 1024 crops (the default for this network); a forward
+    # per loader batch, as the reference runs them, gives the same bits
+    assert hip_model.batch_invariant
+    sl, sr = Evaluation.getFeature(hip_model, _loader(left, right, 50), device, flip=True, group_crops=0)
+    assert torch.equal(sl, fl) and torch.equal(sr, fr)
 
 
 def test_accuracy_within_point_one_on_gpu_embeddings(hip_model_calibrated, device, calibrated_state_dict_np):

@@ -109,6 +109,18 @@ def test_get_feature_contract_with_stub_model():
     assert torch.allclose(fl, ol, atol=1e-6) and torch.allclose(fr, orr, atol=1e-6)
     fl2, _ = Evaluation.getFeature(net, batches, torch.device("cpu"), flip=False)
     assert torch.allclose(fl2, net(L), atol=1e-6)
+    # loader batches grouped into one forward while they hold at most group_crops crops together: same rows, same
+    # order; a stand-in network does not declare batch invariance, so the default is a forward per loader batch
+    calls = []
+    counted = lambda x: (calls.append(x.shape[0]), net(x))[1]  # noqa: E731
+    Evaluation.getFeature(counted, batches, torch.device("cpu"), flip=True)
+    assert calls == [32, 32, 16]
+    for group, want_calls in ((64, [64, 16]), (1024, [80]), (40, [32, 32, 16]), (0, [32, 32, 16])):
+        calls.clear()
+        gl, gr = Evaluation.getFeature(counted, batches, torch.device("cpu"), flip=True, group_crops=group)
+        assert calls == want_calls, (group, calls)
+        assert torch.allclose(gl, fl, atol=1e-6) and torch.allclose(gr, fr, atol=1e-6)
+    assert Evaluation.getFeature(counted, [], torch.device("cpu")) == (None, None)
 
 
 def test_synthetic_generators_are_deterministic():
