@@ -93,7 +93,17 @@ int fra::launch_tail(int dt, const void* x, const void* w6, const float* b6, con
     FRA_REQUIRE(x && w6 && b6 && s6 && w7 && b7 && out, FRA_ERR_ARG, "tail: null pointer");
     FRA_REQUIRE(B > 0, FRA_ERR_ARG, "tail: batch %d", B);
     const int groups = (B + TAIL_IMG - 1) / TAIL_IMG;
-    const dim3 grid(groups, groups <= 8 ? TAIL_C / 32 / TAIL_NW : 1), block(TAIL_NW * 64);
+    // a workgroup's time is a latency chain (inputs, weights of a channel tile, four faces, the next tile's weights, ...):
+    // while the chip has room for it (up to 512 faces on 256 compute units), two workgroups share a group's channel tiles
+    static std::atomic<int> cus_of[64];        // compute units per device (0 = not asked yet)
+    int dev = 0, cus = 0;
+    FRA_HIP(hipGetDevice(&dev));
+    if (dev < 64) cus = cus_of[dev].load(std::memory_order_relaxed);
+    if (cus <= 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        if (dev < 64) cus_of[dev].store(cus, std::memory_order_relaxed);
+    }
+    const dim3 grid(groups, 2 * groups <= cus ? TAIL_C / 32 / TAIL_NW : 1), block(TAIL_NW * 64);
     static std::atomic<uint64_t> lds_set[2];
     if (dt == ACT_F16) {
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(tail_kernel<f16>), TAIL_LDS, lds_set[0])) return rc;
