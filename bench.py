@@ -461,6 +461,29 @@ def main():
                 fn()
             torch.cuda.synchronize()
             extra[name] = {"faces_per_s": round(B * args.steps / (time.perf_counter() - t1), 1)}
+        # crops that start in pinned HOST memory (PCIe-inclusive, never `value`): copy + forward one after the other on
+        # one stream, and through EmbeddingStream, which copies batch i + 1 while batch i runs
+        from face_recognition_amd.streaming import EmbeddingStream
+        hosts = [torch.randint(0, 256, (B, 112, 112, 3), generator=torch.Generator().manual_seed(5 + i), dtype=torch.uint8).pin_memory()
+                 for i in range(3)]
+        es = EmbeddingStream(net, max_batch=B, depth=3)
+
+        def serial():
+            for i in range(args.steps):
+                net.forward_u8(hosts[i % 3].to(dev, non_blocking=True))
+
+        def overlapped():
+            for _ in es.embed(hosts[i % 3] for i in range(args.steps)):
+                pass
+        for name, fn in (("u8_hwc_pinned_host_serial", serial), ("u8_hwc_pinned_host_overlapped", overlapped)):
+            fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            extra[name] = {"faces_per_s": round(B * args.steps / (time.perf_counter() - t1), 1),
+                           "host_bytes_per_face": 112 * 112 * 3}
+        del es, hosts
         result["other_call_shapes"] = extra
     if rank == 0:
         groups, total_ms = per_kernel_profile(net, x, 10, args.dtype)
