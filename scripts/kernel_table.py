@@ -23,7 +23,7 @@ for row in csv.DictReader(open(os.path.join(root, f"profiles/{tag}_kernel_stats.
     elif "linear_l2norm_kernelIDF16_Li16ELi1E" in n or "l2norm_rows_kernel" in n:      # the head is two launches: one row
         st["linear_l2norm_kernel<_Float16, 16, 1>"] = st.get("linear_l2norm_kernel<_Float16, 16, 1>", 0.0) + float(row["AverageNs"]) / 1e3
 names = {"block_kernel<_Float16, 64, 128, 64, 28, 1>": "`block_kernel` 64→128→64 @28², s1 (conv_3, ×4)",
-         "pblock_kernel<_Float16, 64, 128, 64, 28>": "`pblock_kernel` 64→128→64 @28², s1 (conv_3, ×4: row pipeline)",
+         "pblock_kernel<_Float16, 64, 128, 64, 28>": "`pblock_kernel` 64→128→64 @28², s1 (conv_3, ×4: tile pipeline)",
          "block_kernel<_Float16, 128, 256, 128, 14, 1>": "`block_kernel` 128→256→128 @14², s1 (conv_4, ×6)",
          "rblock_kernel<_Float16, 128, 256, 14>": "`rblock_kernel` 128→256→128 @14², s1 (conv_4: six blocks, ONE launch)",
          "block_kernel<_Float16, 64, 128, 64, 56, 2>": "`block_kernel` 64→128→64 @56², s2 (conv_23, ×1)",
