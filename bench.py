@@ -409,7 +409,8 @@ def main():
     x = (torch.randint(0, 256, (B, 3, 112, 112), generator=g, device=dev).float() / 255.0 - 0.5) / 0.5
 
     if args.search_only:
-        s = run_search(args, rank, world, dev, dist)
+        # the full-size gallery: every 500th query (10 planted, 10 random) against the fp32 brute force over all rows
+        s = run_search(args, rank, world, dev, dist, check_sample=500)
         if rank == 0:
             print(json.dumps(s), flush=True)
         return
@@ -533,7 +534,8 @@ def main():
     if not args.no_search:
         if world == 1:      # BASELINE configs[3]: 10k queries x 1M fp16 rows, top-5, one GPU
             result["search_1m"] = run_search(args, rank, world, dev, dist, total=1_000_000, check_sample=40)
-        s = run_search(args, rank, world, dev, dist)
+        # the full-size gallery: every 500th query (10 planted, 10 random) against the fp32 brute force over all rows
+        s = run_search(args, rank, world, dev, dist, check_sample=500)
         if rank == 0:
             result["search"] = s
     if rank == 0 and world == 1 and not args.no_cpu:
