@@ -111,6 +111,31 @@ def getFeature(net, dataloader, device, flip=True, keep_on_device=False, group_c
     return (featureL, featureR) if keep_on_device else (featureL.cpu(), featureR.cpu())
 
 
+def getFeature_u8(net, pair_batches, device, flip=True, keep_on_device=False, max_batch=1024):
+    """``getFeature`` for RAW crops (not in the reference): ``pair_batches`` yields ``(L, R)`` uint8 [b,112,112,3] HWC BGR
+    host tensors (``data_set.dataloader.u8_pair_batches``).  ToTensor + Normalize and the mirrored copy of the flip
+    test-time augmentation (Evaluation.py:50-52) happen inside the first kernel, and the host -> device copy of one
+    batch runs under the forward of the batch before it (``streaming.EmbeddingStream``): a quarter of the bytes of the
+    float route over PCIe and no host-side transform."""
+    from .streaming import EmbeddingStream
+    stream = EmbeddingStream(net, max_batch=max_batch, depth=3, tta=flip, device=torch.device(device))
+    sizes = []
+
+    def crops():
+        for left, right in pair_batches:
+            if left.shape[0] != right.shape[0] or 2 * left.shape[0] > max_batch:
+                raise ValueError(f"pair batch of {left.shape[0]} / {right.shape[0]} crops (at most {max_batch // 2} pairs)")
+            sizes.append(left.shape[0])
+            yield torch.cat([left, right], 0)
+
+    feats = [f for f in stream.embed(crops())]
+    if not feats:
+        return None, None
+    featureL = torch.cat([f[:n] for f, n in zip(feats, sizes)], 0)
+    featureR = torch.cat([f[n:] for f, n in zip(feats, sizes)], 0)
+    return (featureL, featureR) if keep_on_device else (featureL.cpu(), featureR.cpu())
+
+
 def evaluation_10_fold(featureL, featureR, dataset, method="l2_distance"):
     """Evaluation.py:68-99.  ``dataset`` needs ``.folds`` (0..9) and ``.flags`` (+-1).
 

@@ -3,8 +3,10 @@
 the LFW / CFP-FP / AgeDB-30 pair sets with flip-TTA at batch size 50 and print the 10-fold
 ``cos_distance`` accuracy and threshold of each (``test_lfw_agedb_cfpfp.py:57-78``).
 
-The reference reads aligned jpgs and pair lists from disk (``:27-41``); neither ships with it, so
-the pair sets here are synthetic with the same shape: 6000 / 7000 / 6000 pairs, fold = i // (P/10)
+The reference reads aligned jpgs and pair lists from disk (``:27-41``).  Given such data (``--lfw ROOT PAIRS``,
+``--cfp-fp ROOT PAIRS``, ``--agedb30 ROOT PAIRS``) this harness reads it the same way (``data_set/dataloader.py``, a
+``DataLoader`` with two workers).  Neither ships with the reference, so without those options
+the pair sets are synthetic with the same shape: 6000 / 7000 / 6000 pairs, fold = i // (P/10)
 (``data_set/dataloader.py:41,90,135``), half same / half different pairs per fold block, items
 ``[L, flip(L), R, flip(R)]`` of f32 [3,112,112] in [-1,1] (``dataloader.py:57-65``).  Same-pairs are
 two noisy copies of one template, different-pairs two templates.
@@ -83,11 +85,23 @@ class PairLoader:
             yield self.dataset.batch(start, self.batch_size)
 
 
-def load_test_data(batch_size, dataset="Faces_emore", sizes=None, seed=0, noise=0.45, device=None):
-    """(dataloaders, dataset_sizes, dataset) keyed by phase, as ``test_lfw_agedb_cfpfp.py:22-55`` returns them."""
+def load_test_data(batch_size, dataset="Faces_emore", sizes=None, seed=0, noise=0.45, device=None, real=None, workers=2):
+    """(dataloaders, dataset_sizes, dataset) keyed by phase, as ``test_lfw_agedb_cfpfp.py:22-55`` returns them.
+    ``real``: {phase: (root, pair list)} for phases read from disk (``:27-47``: the reference's dataset classes, its
+    transform, ``DataLoader(..., shuffle=False, num_workers=2)``); the other phases are synthetic."""
+    from .data_set import dataloader as dl
     sizes = dict(PHASE_PAIRS if sizes is None else sizes)
-    sets = {name: SyntheticPairs(n, seed=seed + 17 * i, noise=noise, device=device) for i, (name, n) in enumerate(sizes.items())}
-    dataloaders = {name: PairLoader(ds, batch_size) for name, ds in sets.items()}
+    real = dict(real or {})
+    classes = {"LFW": dl.LFW, "CFP_FP": dl.CFP_FP, "AgeDB30": dl.AgeDB30}
+    sets, dataloaders = {}, {}
+    for i, (name, n) in enumerate(sizes.items()):
+        if name in real:
+            root, file_list = real[name]
+            sets[name] = classes[name](root, file_list, transform=dl.test_transform)
+            dataloaders[name] = torch.utils.data.DataLoader(sets[name], batch_size=batch_size, shuffle=False, num_workers=workers)
+        else:
+            sets[name] = SyntheticPairs(n, seed=seed + 17 * i, noise=noise, device=device)
+            dataloaders[name] = PairLoader(sets[name], batch_size)
     dataset_sizes = {name: len(ds) for name, ds in sets.items()}
     print("training and validation data loaded")
     return dataloaders, dataset_sizes, sets
@@ -100,9 +114,9 @@ def load_checkpoint(path: str):
     return torch.load(path, map_location="cpu", weights_only=True)
 
 
-def run(model, device, batch_size=50, sizes=None, seed=0, noise=0.45, method="cos_distance", out=sys.stdout):
+def run(model, device, batch_size=50, sizes=None, seed=0, noise=0.45, method="cos_distance", out=sys.stdout, real=None, workers=2):
     """The loop of ``test_lfw_agedb_cfpfp.py:74-78``.  Returns {phase: (ACCs[10], threshold[10])}."""
-    dataloaders, _, dataset = load_test_data(batch_size, sizes=sizes, seed=seed, noise=noise, device=device)
+    dataloaders, _, dataset = load_test_data(batch_size, sizes=sizes, seed=seed, noise=noise, device=device, real=real, workers=workers)
     model.eval()
     results = {}
     for phase in dataloaders:
@@ -123,6 +137,10 @@ def main(argv=None):
     ap.add_argument("--noise", type=float, default=0.45)
     ap.add_argument("--pairs", type=int, nargs=3, metavar=("LFW", "CFP_FP", "AGEDB30"), default=None)
     ap.add_argument("--method", default="cos_distance", choices=["cos_distance", "l2_distance"])
+    ap.add_argument("--lfw", nargs=2, metavar=("ROOT", "PAIRS"), help="aligned 112x112 LFW images and pairs.txt (:27-29)")
+    ap.add_argument("--cfp-fp", nargs=2, metavar=("ROOT", "PAIRS"), help="CFP-FP images and cfp_fp_pair.txt (:35-37)")
+    ap.add_argument("--agedb30", nargs=2, metavar=("ROOT", "PAIRS"), help="AgeDB-30 images and agedb_30_pair.txt (:39-41)")
+    ap.add_argument("--workers", type=int, default=2, help="DataLoader workers for the phases read from disk")
     args = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("this harness needs a HIP device ('cuda:0'); there is no CPU path")
@@ -135,7 +153,8 @@ def main(argv=None):
         model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     model = model.to(device)
     sizes = dict(zip(PHASE_PAIRS, args.pairs)) if args.pairs else None
-    run(model, device, args.batch_size, sizes, args.data_seed, args.noise, args.method)
+    real = {k: tuple(v) for k, v in (("LFW", args.lfw), ("CFP_FP", args.cfp_fp), ("AgeDB30", args.agedb30)) if v}
+    run(model, device, args.batch_size, sizes, args.data_seed, args.noise, args.method, real=real, workers=args.workers)
 
 
 if __name__ == "__main__":
