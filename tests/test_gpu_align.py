@@ -94,3 +94,40 @@ def test_face_alignment_feeds_the_embedding_network(hip_model, device):
     emb2 = hip_model.forward_u8(torch.from_numpy(np.stack(ar.face_alignment(img, lms))).to(device), tta=True)
     assert torch.equal(emb, emb2)
     assert torch.allclose(emb.norm(dim=1), torch.ones(6, device=device), atol=1e-4)
+
+
+def test_recognize_frame_against_the_oracle_chain(hip_model_calibrated, device, calibrated_state_dict_np):
+    """One frame of the demos (cam_demo.py:79-105): aligned crops -> embeddings (with and without the mirrored copy) ->
+    match, on the device in one call, against the oracle's alignment + forward + broadcast match on the host.  (Weights
+    whose final BatchNorm statistics fit the activations: different faces are then far apart, as with trained weights.)"""
+    hip_model, state_dict_np = hip_model_calibrated, calibrated_state_dict_np
+    from face_recognition_amd.cam_demo import recognize_frame
+    from oracle import matching_ref, mobilefacenet_ref
+    rng = np.random.default_rng(21)
+    img = _frame(rng, 360, 480)
+    lms = _landmarks(rng, 5, 360, 480, scale_range=(1.0, 2.0))
+    crops = np.stack(ar.face_alignment(img, lms))
+    x = torch.from_numpy(crops).permute(0, 3, 1, 2).float().div(255).sub(0.5).div(0.5)
+    embed = lambda t: mobilefacenet_ref.forward(state_dict_np, t)      # noqa: E731
+    for tta in (False, True):
+        want = embed(x)
+        if tta:
+            want = torch.nn.functional.normalize(want + embed(torch.flip(x, dims=[3])))
+        # facebank: faces 3, 0 and 1 enrolled (in that order); faces 2 and 4 are nobody's.  Two thresholds: the demo's
+        # default, and one so strict (d^2 <= 0.0125) that only a face's own enrolment passes it
+        bank = want[[3, 0, 1]].clone()
+        names = np.array(["", "carol", "alice", "bob"])
+        for threshold in (60, 155):
+            labels, score, results = recognize_frame(hip_model, img, lms, bank.to(device), names, threshold=threshold, tta=tta)
+            omin, oidx, oscore = matching_ref.match_broadcast(want, bank, float(threshold))
+            limit = (threshold - 156) / -80
+            assert (omin - limit).abs().min() > 1e-3, "a distance too near the limit to pin the decision"
+            assert results.cpu().tolist() == oidx.tolist()
+            assert labels == [str(names[i + 1]) for i in oidx.tolist()]
+            assert labels[0] == "alice" and labels[1] == "bob" and labels[3] == "carol"
+            assert np.allclose(score.cpu().numpy(), oscore.numpy(), atol=0.1)
+        assert labels[2] == "" and labels[4] == "" and results.cpu().tolist() == [1, 2, -1, 0, -1]
+        # a frame already on the device
+        labels2, _, _ = recognize_frame(hip_model, torch.from_numpy(img).to(device), lms, bank.to(device), names, threshold=155, tta=tta)
+        assert labels2 == labels
+    assert recognize_frame(hip_model, img, [], bank.to(device), names)[0] == []
