@@ -126,3 +126,28 @@ def gather_embeddings(local_emb: torch.Tensor, total: int, group=None) -> torch.
         out = torch.empty((world * maxn, local_emb.shape[1]), dtype=local_emb.dtype, device=local_emb.device)
         dist.all_gather_into_tensor(out, pad, group=group)
     return torch.cat([out[r * maxn: r * maxn + (e - b)] for r, (b, e) in enumerate(sizes)], 0)
+
+
+def get_feature_sharded(net, batches_for: Callable, total_pairs: int, device, flip: bool = True, group=None
+                        ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Verification features with the PAIRS split over the ranks (Evaluation.py:36-66 run data parallel): this rank embeds
+    pairs ``split_batch(total_pairs)`` -- ``batches_for(lo, hi)`` yields their loader batches ``[L, flip(L), R,
+    flip(R)]`` -- and one all-gather per side assembles ``featureLs`` / ``featureRs`` [total_pairs, E] in pair order on
+    every rank, on the host, where the fold-by-fold threshold search of ``evaluation_10_fold`` runs.  No other
+    collective; the result does not depend on the number of ranks."""
+    from .Evaluation import getFeature
+    lo, hi = split_batch(total_pairs, group)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    fl = fr = None
+    if hi > lo:
+        fl, fr = getFeature(net, batches_for(lo, hi), device, flip=flip, keep_on_device=True)
+    if world > 1:
+        # a rank without pairs (fewer pairs than ranks) still takes part in the gathers: it needs the feature width
+        on = torch.device(device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        width = torch.tensor([0 if fl is None else fl.shape[1]], dtype=torch.int64, device=on)
+        dist.all_reduce(width, op=dist.ReduceOp.MAX, group=group)
+        if fl is None:
+            fl = fr = torch.zeros((0, int(width.item())), dtype=torch.float32, device=torch.device(device))
+    if fl is None:
+        raise ValueError("get_feature_sharded: no pairs")
+    return gather_embeddings(fl, total_pairs, group).cpu(), gather_embeddings(fr, total_pairs, group).cpu()

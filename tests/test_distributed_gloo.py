@@ -75,6 +75,19 @@ def _worker_small(rank, world, port, out_dir, n):
 
         sg = sharded.ShardedGallery(n, local_search, merge=merge)
         d, i = sg.search(torch.from_numpy(q), K)
+        # verification features with the pairs split over the ranks (3 pairs over 4 ranks: one rank has none)
+        w = torch.randn((3 * 112 * 112, 8), generator=torch.Generator().manual_seed(1)) * 0.01
+        net = lambda x: torch.nn.functional.normalize(x.reshape(x.shape[0], -1) @ w)      # noqa: E731
+        for pairs, name in ((23, "v"), (3, "w")):
+            left, right, _ = synthetic.pair_crops(40, seed=8)
+            L, R = torch.from_numpy(left[:pairs]), torch.from_numpy(right[:pairs])
+
+            def batches_for(lo, hi, L=L, R=R):
+                for s0 in range(lo, hi, 4):
+                    l, r = L[s0:min(s0 + 4, hi)], R[s0:min(s0 + 4, hi)]
+                    yield [l, torch.flip(l, dims=[3]), r, torch.flip(r, dims=[3])]
+            fl, fr = sharded.get_feature_sharded(net, batches_for, pairs, torch.device("cpu"), flip=True)
+            np.savez(os.path.join(out_dir, f"{name}{rank}.npz"), fl=fl.numpy(), fr=fr.numpy())
         lo, hi = sharded.split_batch(10)              # 10 crops over 4 ranks: 3, 3, 2, 2
         emb = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 4)
         allemb = sharded.gather_embeddings(emb, 10)
@@ -102,6 +115,18 @@ def test_sharded_search_four_ranks_uneven_and_short_shards(tmp_path):
         assert np.array_equal(rs[0]["i"], bi) and (rs[0]["i"] >= 0).all()
         assert np.allclose(rs[0]["d"], bd, atol=1e-5)
         assert sorted(tuple(r["bounds"]) for r in rs)[-1][1] == n
+        # verification features: every rank holds all pairs in order, equal to one process embedding them all
+        from face_recognition_amd import Evaluation
+        w = torch.randn((3 * 112 * 112, 8), generator=torch.Generator().manual_seed(1)) * 0.01
+        net = lambda x: torch.nn.functional.normalize(x.reshape(x.shape[0], -1) @ w)      # noqa: E731
+        for pairs, name in ((23, "v"), (3, "w")):
+            left, right, _ = synthetic.pair_crops(40, seed=8)
+            L, R = torch.from_numpy(left[:pairs]), torch.from_numpy(right[:pairs])
+            one = Evaluation.getFeature(net, [[L, torch.flip(L, dims=[3]), R, torch.flip(R, dims=[3])]], torch.device("cpu"), flip=True)
+            for r in range(world):
+                v = np.load(out / f"{name}{r}.npz")
+                assert v["fl"].shape == (pairs, 8)
+                assert np.allclose(v["fl"], one[0].numpy(), atol=1e-6) and np.allclose(v["fr"], one[1].numpy(), atol=1e-6)
 
 
 def test_sharded_search_two_ranks(tmp_path):
