@@ -103,6 +103,21 @@ def test_batch_1024_rows_match_small_batches(hip_model, device):
     assert torch.equal(full[300:500], mid)
 
 
+def test_rows_do_not_depend_on_the_batch_at_every_launcher_limit(hip_model, device):
+    """Batch sizes on both sides of every limit at which the library changes kernels or workgroup shapes (short / tall
+    bands at 18 and 36, conv_5's bands / two / four stacked images at 36 and 512, the conv_4 chain at 36, conv_3's
+    pipeline ranges 193-256, 385-512, 641-, a second image per workgroup above 256 / 1024, batches that are no multiple
+    of a stack): every face's embedding is the bits it has in the largest batch."""
+    B = 1025
+    x = torch.from_numpy(synthetic.make_crops(41, 29)).to(device).repeat(25, 1, 1, 1).contiguous()
+    x += torch.linspace(-0.3, 0.3, B, device=device).view(B, 1, 1, 1)
+    full = hip_model(x).cpu()
+    assert torch.isfinite(full).all()
+    for b in (1, 2, 3, 18, 19, 36, 37, 38, 39, 192, 193, 256, 257, 384, 385, 511, 512, 513, 514, 640, 641, 1023, 1024):
+        assert torch.equal(hip_model(x[:b].contiguous()).cpu(), full[:b]), b
+        assert torch.equal(hip_model(x[B - b:].contiguous()).cpu(), full[B - b:]), -b
+
+
 def test_chained_and_per_block_launches_agree_bit_for_bit(hip_model, device):
     """conv_4's six blocks as one register-resident launch (large batches) vs six launches: same rows; and the
     launch plan says which of the two a batch size gets."""
