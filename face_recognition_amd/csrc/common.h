@@ -208,6 +208,9 @@ int pack_rblock(int dt, int c, int cexp, const float* w1, const float* b1, const
 int launch_rblock(int dt, int c, int cexp, int h, const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s);
 // true when `nblk` > 1 blocks of this shape should run as one launch for a batch of B images
 bool rblock_chain_pays(int c, int cexp, int h, int B);
+// blocks the next launch covers when `remaining` identical blocks are left: all of them (whole-image workgroups), two
+// (bands of a small batch, each computing its neighbours' nearest rows itself), or one
+int rblock_chain_blocks(int c, int cexp, int h, int B, int remaining);
 // fused head: stem conv (3->64, 3x3 s2, PReLU) + depthwise 3x3 (64 ch, PReLU) -> out T NHWC [B,56,56,64].
 // x: n_src crops, f32 NCHW in [-1,1] or (x_is_u8) uint8 HWC; images n_src..B-1 are mirrored copies of images 0..B-n_src-1
 struct StemDwParams {

@@ -141,8 +141,12 @@ extern "C" int fra_dbg_read(void* dst, size_t bytes) {
 // slots apart: the 9 slots between two images are the lower border row of the one and the upper border row of the
 // other.  The two activation image sets are G * 64 slots apart for the same reason; 16 slots follow the second one
 // (its last border row, and the reads of lanes that have no pixel).
-template <int H, int TR, int G> constexpr int rb_es_bytes() {
-    return G > 1 ? G * 64 * 144 : (TR + 2) * block_pitch<H, 1>() * 144;
+// CH > 1 (bands of small batches): CH blocks per launch.  A band's workgroup computes the first block on CH - 1 more rows
+// above and below (from CH more input rows each side), the next on one row less each side, ...: no row ever comes from
+// another workgroup, at the price of computing the rows next to a band twice -- which costs a small batch nothing, while
+// every launch it saves is some 9 microseconds.
+template <int H, int TR, int G, int CH = 1> constexpr int rb_es_bytes() {
+    return G > 1 ? G * 64 * 144 : (TR + 2 * CH) * block_pitch<H, 1>() * 144;
 }
 // main tiles (expand input == project output) of a workgroup: whole rows, padded to 8, 16 or 32 lanes, 32 lanes per tile
 template <int H, int TR, int G> constexpr int rb_main_tiles() {
@@ -153,23 +157,40 @@ template <int H, int TR, int G> constexpr int rb_main_tiles() {
 template <int H, int TR, int NW, int G> constexpr bool rb_flags() {
     return TR == H && RB_FLAGS && rb_main_tiles<H, TR, G>() > NW / 2 && rb_main_tiles<H, TR, G>() < NW;
 }
-template <int H, int TR, int NW, int G> constexpr int rb_images_bytes() {
+template <int H, int TR, int NW, int G, int CH = 1> constexpr int rb_images_bytes() {
     return G > 1 ? (2 * rb_es_bytes<H, TR, G>() + 16 * 144 + 1023) / 1024 * 1024
-                 : (rb_flags<H, TR, NW, G>() ? 2 : 1) * rb_es_bytes<H, TR, G>();
+                 : (rb_flags<H, TR, NW, G>() ? 2 : 1) * rb_es_bytes<H, TR, G, CH>();
 }
-template <int C, int CEXP, int H, int TR, int NW, int G = 1> constexpr int rblock_lds_bytes() {
-    return rb_images_bytes<H, TR, NW, G>() + 2 * RbPkg<C>::BYTES + (rb_flags<H, TR, NW, G>() ? 128 : 0);
+template <int C, int CEXP, int H, int TR, int NW, int G = 1, int CH = 1> constexpr int rblock_lds_bytes() {
+    return rb_images_bytes<H, TR, NW, G, CH>() + 2 * RbPkg<C>::BYTES + (rb_flags<H, TR, NW, G>() ? 128 : 0) +
+           (CH > 1 ? (rb_main_tiles<H, TR, G>() + CH - 1) * 2 * 64 * (C / 32) * 16 : 0);
 }
 
-template <typename T, int C, int CEXP, int H, int TR, int NW, int G = 1>
+template <typename T, int C, int CEXP, int H, int TR, int NW, int G, int CH>
+__device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk);
+
+template <typename T, int C, int CEXP, int H, int TR, int NW, int G = 1, int CH = 1>
 __global__ __launch_bounds__(NW * 64, 2)
 void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk) {
+    rblock_body<T, C, CEXP, H, TR, NW, G, CH>(X, WP, O, B, nblk);
+}
+
+// the same body with the register budget of exactly two waves per SIMD spelled out (the several-blocks-per-band
+// configuration: left to itself the compiler aims at three waves and spills)
+template <typename T, int C, int CEXP, int H, int TR, int NW, int G, int CH>
+__global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void rblock_kernel_w2(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk) {
+    rblock_body<T, C, CEXP, H, TR, NW, G, CH>(X, WP, O, B, nblk);
+}
+
+template <typename T, int C, int CEXP, int H, int TR, int NW, int G, int CH>
+__device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk) {
     typedef typename vec8<T>::type V8;
     typedef typename vec4<T>::type V4;
     typedef RbPkg<C> PK;
     constexpr int W = H;
     constexpr bool WHOLE = (TR == H);                      // the band is the whole image: no halo rows
-    constexpr int RIN = TR + 2;                            // LDS rows: band rows + one row above and below
+    constexpr int RIN = TR + 2 * CH;                       // LDS rows: band rows + CH rows above and below
     // a tile is RPT whole rows, each padded to POW (a power of two) lanes
     constexpr int POW = W <= 8 ? 8 : (W <= 16 ? 16 : 32), RPT = 32 / POW;
     // STACK: subtile st of every tile belongs to images st GP .. st GP + GP - 1 of the workgroup's G, tile t to rows
@@ -178,11 +199,13 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     constexpr int GP = STACK ? G / 2 : 1;
     constexpr int MTO = rb_main_tiles<H, TR, G>();         // main tiles: expand input == project output
     static_assert(MTO == (STACK ? (GP * H + 1) / 2 : (TR + RPT - 1) / RPT), "tiles of whole rows");
-    constexpr int HT = WHOLE ? 0 : (RPT >= 2 ? 1 : 2);     // halo tiles (rows y0 - 1 and y0 + TR)
+    // halo tiles: tile MTO + j holds the rows y0 - 1 - j and y0 + TR + j (RPT == 1: a tile each for y0 - 1 and y0 + TR)
+    constexpr int HT = WHOLE ? 0 : (RPT >= 2 ? CH : 2);
+    static_assert(CH == 1 || (!WHOLE && G == 1 && POW == 16 && RB_FLAGS), "several blocks per band launch: built for 14-wide maps");
     constexpr int MTI = MTO + HT;
     constexpr int KS = C / 32, NT16 = C / 16, NCH = CEXP / 64;
     constexpr int PITCH = STACK ? W + 1 : block_pitch<H, 1>(), SLOT = 144;
-    constexpr int ES_BYTES = rb_es_bytes<H, TR, G>();
+    constexpr int ES_BYTES = rb_es_bytes<H, TR, G, CH>();
     static_assert(STACK || ES_BYTES == RIN * PITCH * SLOT, "band rows and their borders");
     // FL: no workgroup-wide barriers in the slice loop.  A wave's expand stage writes its tile's rows, its depthwise
     // stage reads those and the two neighbouring tiles' rows: it waits for those two waves only (flags in LDS), and
@@ -190,11 +213,13 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     // one.  The tile-less last wave copies the weight packages and tells the others when one has landed.
     constexpr bool FL = rb_flags<H, TR, NW, G>();
     constexpr int NIMG = FL ? 2 : 1;
-    constexpr int IMG_BYTES = rb_images_bytes<H, TR, NW, G>();
+    constexpr int IMG_BYTES = rb_images_bytes<H, TR, NW, G, CH>();
     constexpr int OFF_PKG = IMG_BYTES, OFF_FLAGS = OFF_PKG + 2 * PK::BYTES;
     static_assert(!STACK || (FL && H == 7 && (G == 2 || G == 4)), "stacked images: 7 x 7 maps, whole-image workgroups with flags");
     static_assert(IMG_BYTES >= NIMG * ES_BYTES, "both activation images fit");
-    constexpr int LDS_BYTES = OFF_FLAGS + (FL ? 128 : 0);
+    constexpr int OFF_XCH = OFF_FLAGS + (FL ? 128 : 0);
+    constexpr int XCH_BYTES = CH > 1 ? (MTO + CH - 1) * 2 * 64 * KS * 16 : 0;   // per output tile and subtile: a lane's KS fragments
+    constexpr int LDS_BYTES = OFF_XCH + XCH_BYTES;
     constexpr int MTIW = (MTI + NW - 1) / NW;              // input tiles per wave
     // with at most NW / 2 input tiles two waves share one and expand two of the slice's four channel tiles each
     constexpr bool ESPLIT = MTI <= NW / 2;
@@ -203,10 +228,12 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     static_assert(MTO <= NW, "one output tile per wave");
     // with at most NW / 4 main tiles the two waves that share an input tile also share its depthwise / project work:
     // one 16-pixel subtile each (pixels are columns of every product, so nothing about a value changes)
-    constexpr bool SSPLIT = ESPLIT && 4 * MTO <= NW;
+    constexpr bool SSPLIT = ESPLIT && 4 * (MTO + CH - 1) <= NW;
+    // (CH > 1) the two waves of a tile hand each other their subtile of a block's output through LDS (OFF_XCH)
+    static_assert(CH == 1 || SSPLIT, "several blocks per band launch: two waves per tile, a subtile each");
     constexpr int NSUB = SSPLIT ? 1 : 2;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static_assert(LDS_BYTES == rblock_lds_bytes<C, CEXP, H, TR, NW, G>(), "the launcher's LDS size is this map's");
+    static_assert(LDS_BYTES == rblock_lds_bytes<C, CEXP, H, TR, NW, G, CH>(), "the launcher's LDS size is this map's");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -266,13 +293,14 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
             if (ti < MTO) {
                 const int orow = ti * RPT + rr;
                 ok = orow < TR;
-                lr = 1 + orow;
+                lr = CH + orow;
                 gy = y0 + orow;
             } else {
-                const int which = POW == 32 ? ti - MTO : rr;   // 0: the row above the band, 1: the row below
+                const int which = POW == 32 ? ti - MTO : rr;   // 0: a row above the band, 1: a row below
+                const int lvl = POW == 32 ? 0 : ti - MTO;      // how far from the band
                 ok = ti < MTI && which < 2;
-                lr = which ? TR + 1 : 0;
-                gy = which ? y0 + TR : y0 - 1;
+                lr = which ? CH + TR + lvl : CH - 1 - lvl;
+                gy = which ? y0 + TR + lvl : y0 - 1 - lvl;
             }
             ok = ok && xx < W && gy >= 0 && gy < H;
             lds_px[tt][st] = ok ? (lr * PITCH + xx + 1) * SLOT + 32 * g4 : -1;
@@ -310,7 +338,9 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     {
         const int oy = wt * RPT + m16 / POW, ox = m16 % POW;
         const int sub = SSPLIT ? en * ST1 : 0;                                 // (SSPLIT) this wave's subtile
-        tb = (oy * PITCH + ox + (g4 < 2 ? g4 : 2)) * SLOT + sub;
+        tb = ((CH - 1 + oy) * PITCH + ox + (g4 < 2 ? g4 : 2)) * SLOT + sub;
+        // (CH > 1) the first halo tile as an OUTPUT tile: subtile 0 is row y0 - 1 (LDS row CH - 1), subtile 1 row y0 + TR
+        if (CH > 1 && wt == MTO) tb = ((CH - 2 + en * (TR + 1)) * PITCH + ox + (g4 < 2 ? g4 : 2)) * SLOT;
         if constexpr (STACK) {                             // pixel slot less one row and one slot
             const int pr = 2 * wt + (m16 >> 3);
             tb = ((pr / H) * 64 + (pr % H) * PITCH + (m16 & 7) + (g4 < 2 ? g4 : 2)) * SLOT;
@@ -318,8 +348,9 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     }
     f32x4 pacc[NSUB][NT16];  // tile n of subtile st, register i <-> output channel 16 n + 4 g + i
 
-    auto expand = [&](int buf, int ioff) {                 // ioff: byte offset of the activation image to write
-        if (we >= MTI || en >= 2) return;                  // wave-uniform
+    // blk: (CH > 1) block of the launch being computed: its tiles shrink by one halo tile per block
+    auto expand = [&](int buf, int ioff, int blk = 0) {    // ioff: byte offset of the activation image to write
+        if (we >= MTI - blk || en >= 2) return;            // wave-uniform
         const int base = OFF_PKG + buf * PK::BYTES;
         const int w1l = base + (16 * (g4 & 1) + m16) * PK::PW1 + 16 * (g4 >> 1);
         const int pl = base + PK::OFF_B1 + 16 * g4;
@@ -334,8 +365,8 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
             }
         }
     };
-    auto dwproject = [&](int buf, int ioff) {
-        if (!dw_active) return;                            // wave-uniform
+    auto dwproject = [&](int buf, int ioff, int blk = 0) {
+        if (CH == 1 ? !dw_active : (we >= MTO + CH - 1 - blk || en >= 2)) return;   // wave-uniform
         const int base = OFF_PKG + buf * PK::BYTES;
         DwStage<T, 64, NT16, PK::PW3, ST1, PITCH * SLOT, 4, NSUB> dw;
         dw.tb = tb + ioff;
@@ -475,6 +506,7 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
         int p = 0;                                             // package of the current slice
 #pragma unroll 1
         for (int b = 0; b < nblk; ++b) {
+            const int blk = CH > 1 ? b : 0;
 #pragma unroll
             for (int st = 0; st < NSUB; ++st)
 #pragma unroll
@@ -491,7 +523,7 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
                 RB_T(t0);
                 RB_ACC(5, ts, t0);
 #ifndef RB_ABL_NO_EXPAND
-                expand(buf, 0);
+                expand(buf, 0, blk);
 #endif
                 RB_T(t1);
                 RB_ACC(0, t0, t1);
@@ -504,17 +536,42 @@ void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
                 RB_T(t2);
                 RB_ACC(1, t1, t2);
 #ifndef RB_ABL_NO_DW
-                dwproject(buf, 0);
+                dwproject(buf, 0, blk);
 #endif
                 RB_T(t3);
                 RB_ACC(2, t2, t3);
-                if (c == NCH - 1 && dw_active) block_epilogue(buf, b == nblk - 1, img);
+                const bool dwa = CH == 1 ? dw_active : (we < MTO + CH - 1 - blk && en < 2);      // wave-uniform
+                if (c == NCH - 1 && dwa) block_epilogue(buf, b == nblk - 1, img);
+                if constexpr (CH > 1) {
+                    // the block's output for the next block's expand stage: this wave holds ITS subtile of the tile, the
+                    // wave it shares the tile with the other one
+                    if (c == NCH - 1 && b + 1 < nblk && dwa) {
+                        char* xo = lds + OFF_XCH + ((we * 2 + en) * 64 + lane) * (KS * 16);
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            if (en) *reinterpret_cast<V8*>(xo + 16 * ks) = xf[0][1][ks];      // wave-uniform
+                            else *reinterpret_cast<V8*>(xo + 16 * ks) = xf[0][0][ks];
+                        }
+                    }
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 RB_T(t4);
                 RB_ACC(3, t3, t4);
 #ifndef RB_ABL_NO_BARRIER2
                 __syncthreads();                               // image free, next package visible
 #endif
+                if constexpr (CH > 1) {
+                    if (c == NCH - 1 && b + 1 < nblk && dwa) {
+                        const char* xi = lds + OFF_XCH + ((we * 2 + (en ^ 1)) * 64 + lane) * (KS * 16);
+                        if (en) {
+#pragma unroll
+                            for (int ks = 0; ks < KS; ++ks) xf[0][0][ks] = *reinterpret_cast<const V8*>(xi + 16 * ks);
+                        } else {
+#pragma unroll
+                            for (int ks = 0; ks < KS; ++ks) xf[0][1][ks] = *reinterpret_cast<const V8*>(xi + 16 * ks);
+                        }
+                    }
+                }
                 RB_T(t5);
                 RB_ACC(4, t4, t5);
             }
@@ -549,14 +606,14 @@ static int rb_compute_units() {
     return cus;
 }
 
-template <typename T, int C, int CEXP, int H, int TR, int NW, int G = 1>
+template <typename T, int C, int CEXP, int H, int TR, int NW, int G = 1, int CH = 1>
 static int launch_rblock_cfg(const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s) {
     constexpr int bands = H / TR;
-    constexpr int lds = rblock_lds_bytes<C, CEXP, H, TR, NW, G>();
-    FRA_REQUIRE(nblk == 1 || (TR == H && rb_main_tiles<H, TR, G>() > NW / 2), FRA_ERR_ARG,
+    constexpr int lds = rblock_lds_bytes<C, CEXP, H, TR, NW, G, CH>();
+    FRA_REQUIRE(CH > 1 ? nblk == CH : (nblk == 1 || (TR == H && rb_main_tiles<H, TR, G>() > NW / 2)), FRA_ERR_ARG,
                 "rblock: %d blocks per launch need whole-image workgroups with a tile per wave", nblk);
     static_assert(G == 1 || rb_flags<H, TR, NW, G>(), "stacked images run on the flag-synchronised loop");
-    auto kern = rblock_kernel<T, C, CEXP, H, TR, NW, G>;
+    auto kern = CH > 1 ? rblock_kernel_w2<T, C, CEXP, H, TR, NW, G, CH> : rblock_kernel<T, C, CEXP, H, TR, NW, G, CH>;
     static std::atomic<uint64_t> lds_set;      // per instantiation: devices whose LDS limit is raised
     static std::atomic<int> slots_of[64];      // resident workgroups per band, per device (0 = not asked yet)
     int dev = 0;
@@ -595,12 +652,22 @@ static int rb_stack_choice(int B, int cus) {
     return B <= 2 * RB_STACK2_PER_CU * cus ? 2 : 4;
 }
 
+// FRA_RB_BAND_CHAIN=0: small batches run one block per launch (measurements)
+static bool rb_band_chain() {
+    static const bool on = [] { const char* e = getenv("FRA_RB_BAND_CHAIN"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 // conv_4 (128 -> 256 -> 128 on 14 x 14): bands of 2 rows (7 workgroups per image) while those fit the chip in
 // one go, bands of 7 rows (2 per image) while those do, whole images beyond
 template <typename T>
 static int launch_rblock_t(int c, int cexp, int h, const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s) {
     const int cus = rb_compute_units();
     if (c == 128 && cexp == 256 && h == 14) {
+        // two blocks per launch of two-row bands (each band computes its neighbours' nearest rows itself); not in place:
+        // other workgroups read the input rows around their bands
+        if (nblk == 2 && (int64_t)B * 7 <= cus && x != out && rb_band_chain())
+            return launch_rblock_cfg<T, 128, 256, 14, 2, 8, 1, 2>(x, wp, 2, out, B, s);
         if (nblk > 1) return launch_rblock_cfg<T, 128, 256, 14, 14, RB_NW_WHOLE>(x, wp, nblk, out, B, s);
         if ((int64_t)B * 7 <= cus) return launch_rblock_cfg<T, 128, 256, 14, 2, 8>(x, wp, 1, out, B, s);
         if ((int64_t)B * 2 <= cus) return launch_rblock_cfg<T, 128, 256, 14, 7, 8>(x, wp, 1, out, B, s);
@@ -615,6 +682,13 @@ static int launch_rblock_t(int c, int cexp, int h, const void* x, const void* wp
     }
     FRA_REQUIRE(false, FRA_ERR_ARG, "rblock: no kernel for c=%d cexp=%d h=%d", c, cexp, h);
     return FRA_ERR_ARG;
+}
+
+int rblock_chain_blocks(int c, int cexp, int h, int B, int remaining) {
+    if (remaining < 2) return 1;
+    if (rblock_chain_pays(c, cexp, h, B)) return remaining;                 // whole images: the rest of the run in one launch
+    if (c == 128 && cexp == 256 && h == 14 && (int64_t)B * 7 <= rb_compute_units() && rb_band_chain()) return 2;
+    return 1;
 }
 
 bool rblock_chain_pays(int c, int cexp, int h, int B) {

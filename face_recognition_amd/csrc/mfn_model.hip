@@ -524,6 +524,23 @@ static WsPlan plan_ws(int b, int E, bool tta) {
     return p;
 }
 
+// Which activation buffers a launch reads and writes.  The ops of the un-fused schedule name theirs; the fused blocks
+// alternate between BUF_P0 and BUF_P1 per LAUNCH (a launch may cover several blocks), starting from where the stem wrote.
+struct ActCursor {
+    int cur = -1;
+    void next(const Op& o, int* in_id, int* out_id) {
+        *in_id = o.in;
+        *out_id = o.out;
+        if (o.kind == OP_BLOCK && cur >= 0) {
+            *in_id = cur;
+            *out_id = cur == BUF_P0 ? BUF_P1 : BUF_P0;
+        } else if (o.kind == OP_TAIL && cur >= 0) {
+            *in_id = cur;
+        }
+        if (o.kind == OP_STEMDW || (o.kind == OP_BLOCK && cur >= 0)) cur = *out_id;
+    }
+};
+
 static int slice_size(const mfn_handle* h, int B) { return (h->chunk > 0 && h->chunk < B) ? h->chunk : B; }
 
 // b = images in the activation buffers; x holds n_src source crops (b == n_src, or 2 n_src with mirrored copies)
@@ -532,15 +549,18 @@ static int slice_size(const mfn_handle* h, int B) { return (h->chunk > 0 && h->c
 static int ops_in_launch(const mfn_handle* h, int i, int b, int limit) {
     const Op& o = h->ops()[i];
     if (o.kind != OP_BLOCK || !o.rblock || o.chain_len - o.chain_pos < 2 || !h->chain) return 1;
-    if (!rblock_chain_pays(o.cin, o.cexp, o.hin, b)) return 1;
-    const int n = o.chain_len - o.chain_pos;
-    return n < limit ? n : limit;
+    const int left = o.chain_len - o.chain_pos;
+    return rblock_chain_blocks(o.cin, o.cexp, o.hin, b, left < limit ? left : limit);
 }
 
 // `nblk` > 1: op o and the nblk - 1 ops after it as one launch, written where the last of them writes
+// in_id / out_id >= 0: the activation buffers a fused block (or the tail) reads and writes, in place of the op's own --
+// a launch that covers several blocks moves the activation once, so the two buffers alternate per LAUNCH
 static int run_op(const mfn_handle* h, const Op& o, const void* x, int x_is_u8, int n_src, float* out, char* ws,
-                  const WsPlan& p, int b, hipStream_t s, int nblk = 1) {
+                  const WsPlan& p, int b, hipStream_t s, int nblk = 1, int in_id = -1, int out_id = -1) {
     auto buf = [&](int id) -> void* { return ws + p.off[id]; };
+    if (in_id < 0) in_id = o.in;
+    if (out_id < 0) out_id = o.out;
     switch (o.kind) {
         case OP_STEM:
             FRA_REQUIRE(!x_is_u8 && b == n_src, FRA_ERR_STATE, "uint8 input and fused flip-TTA need the fused schedule");
@@ -555,13 +575,12 @@ static int run_op(const mfn_handle* h, const Op& o, const void* x, int x_is_u8, 
         case OP_LINEAR:
             return launch_linear_l2norm(h->dt, buf(o.in), o.w, o.bias, out, b, o.cin, o.cout, s);
         case OP_BLOCK:
-            if (o.rblock)   // blocks ping-pong between two buffers: an even count ends in the buffer it started from
-                return launch_rblock(h->dt, o.cin, o.cexp, o.hin, buf(o.in), o.rb, nblk, buf((nblk & 1) ? o.out : o.in), b, s);
-            return launch_block(h->dt, o.bp, buf(o.in), buf(o.out), b, s);
+            if (o.rblock) return launch_rblock(h->dt, o.cin, o.cexp, o.hin, buf(in_id), o.rb, nblk, buf(out_id), b, s);
+            return launch_block(h->dt, o.bp, buf(in_id), buf(out_id), b, s);
         case OP_STEMDW:
             return launch_stemdw(h->dt, o.sp, x, x_is_u8, n_src, buf(o.out), b, s);
         case OP_TAIL:
-            return launch_tail(h->dt, buf(o.in), o.tl[0], (const float*)o.tl[1], (const float*)o.tl[2], o.tl[3],
+            return launch_tail(h->dt, buf(in_id), o.tl[0], (const float*)o.tl[1], (const float*)o.tl[2], o.tl[3],
                                (const float*)o.tl[4], buf(o.out), b, s);
     }
     return FRA_ERR_ARG;
@@ -609,9 +628,12 @@ static int forward(mfn_handle* h, const void* x, int x_is_u8, int B, bool tta, f
         float* os = out + (size_t)b0 * h->E;
         float* emb = tta ? reinterpret_cast<float*>(static_cast<char*>(ws) + p.emb) : os;
         if (op_ms) FRA_HIP(hipEventRecord(ev[0], s));
+        ActCursor act;
         for (int i = 0; i < nops;) {
             const int n = ops_in_launch(h, i, nb, nops - i);
-            rc = run_op(h, h->ops()[i], xs, x_is_u8, b, emb, static_cast<char*>(ws), p, nb, s, n);
+            int in_id, out_id;
+            act.next(h->ops()[i], &in_id, &out_id);
+            rc = run_op(h, h->ops()[i], xs, x_is_u8, b, emb, static_cast<char*>(ws), p, nb, s, n, in_id, out_id);
             if (rc) return rc;
             if (i + n == nops && tta) {   // l2_norm(emb + emb_mirror): facebank.py:62
                 rc = launch_add_l2norm(emb, emb + (size_t)b * h->E, os, b, h->E, s);
@@ -760,16 +782,20 @@ int mfn_debug_prefix(mfn_handle* h, const float* x, int B, int n_ops, float* out
     FRA_DEVICE(h->device);
     const WsPlan p = plan_ws(B, h->E, false);
     hipStream_t s = (hipStream_t)stream;
+    ActCursor act;
+    int out_id = -1;
     for (int i = 0; i < n_ops;) {
         const int n = ops_in_launch(h, i, B, n_ops - i);
-        rc = run_op(h, h->ops()[i], x, 0, B, nullptr, static_cast<char*>(ws), p, B, s, n);
+        int in_id;
+        act.next(h->ops()[i], &in_id, &out_id);
+        rc = run_op(h, h->ops()[i], x, 0, B, nullptr, static_cast<char*>(ws), p, B, s, n, in_id, out_id);
         if (rc) return rc;
         i += n;
     }
     const Op& o = h->ops()[n_ops - 1];
     const int64_t per = (int64_t)o.hout * o.hout * o.cout;
     if (numel_per_image) *numel_per_image = per;
-    return launch_to_f32(h->dt, static_cast<char*>(ws) + p.off[o.out], out_f32, per * B, s);
+    return launch_to_f32(h->dt, static_cast<char*>(ws) + p.off[out_id], out_f32, per * B, s);
 }
 
 int mfn_destroy(mfn_handle* h) {

@@ -132,7 +132,7 @@ def _rblock_packages(lib, code, c, cexp, w1, b1, s1, w2, b2, s2, w3, b3):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
-@pytest.mark.parametrize("H,B", [(14, 2), (14, 37), (14, 129), (14, 300), (7, 2), (7, 37), (7, 131), (7, 300), (7, 515), (7, 1030)])
+@pytest.mark.parametrize("H,B", [(14, 1), (14, 2), (14, 36), (14, 37), (14, 129), (14, 300), (7, 2), (7, 37), (7, 131), (7, 300), (7, 515), (7, 1030)])
 def test_rblock_chain(device, dt, H, B):
     """Three residual blocks (128 -> 256 -> 128 on 14 x 14 or 7 x 7) back to back: one launch with the activation kept
     in registers == three launches bit for bit, for every configuration the batch size selects (14 x 14: 2-row bands,
@@ -161,12 +161,21 @@ def test_rblock_chain(device, dt, H, B):
     per = pks[0].numel()
     xd = x.permute(0, 2, 3, 1).contiguous().to(tdt).to(device)
     # one launch per block (band configuration by batch size)
-    cur = xd
+    cur, after = xd, []
     for i in range(nblk):
         nxt = torch.full_like(xd, float("nan"))
         _lib.check(lib.mfn_op_rblock(code, c, cexp, H, cur.data_ptr(), pk.data_ptr() + i * per, 1, nxt.data_ptr(), B,
                                      stream(device)), "rblock")
         cur = nxt
+        after.append(nxt)
+    # two blocks per launch, not in place: for a small batch of 14 x 14 maps these are two-row bands that compute their
+    # neighbours' nearest rows themselves (blocks 0-1, then blocks 1-2 from the first block's output)
+    for first, src in ((0, xd), (1, after[0])):
+        two = torch.full_like(xd, float("nan"))
+        _lib.check(lib.mfn_op_rblock(code, c, cexp, H, src.data_ptr(), pk.data_ptr() + first * per, 2, two.data_ptr(), B,
+                                     stream(device)), "rblock, two blocks")
+        torch.cuda.synchronize()
+        assert torch.equal(two, after[first + 1]), first
     # one launch for all three, written over its own input
     chained = xd.clone()
     _lib.check(lib.mfn_op_rblock(code, c, cexp, H, chained.data_ptr(), pk.data_ptr(), nblk, chained.data_ptr(), B,

@@ -127,15 +127,23 @@ def test_chained_and_per_block_launches_agree_bit_for_bit(hip_model, device):
     names = [r[0] for r in hip_model.op_table()]
     first = names.index("conv_4.model.0")
     assert plan[first:first + 6] == [first] * 6                       # one launch covers the six blocks
-    assert hip_model.launch_plan(8) == list(range(len(names)))        # small batch: one launch per op
+    # small batch: conv_4 as three launches of two blocks each (two-row bands that compute their neighbours' nearest
+    # rows themselves), every other op a launch of its own
+    small = list(range(len(names)))
+    for j in range(6):
+        small[first + j] = first + 2 * (j // 2)
+    assert hip_model.launch_plan(8) == small
     hip_model.set_chain(False)
     try:
-        assert hip_model.launch_plan(150) == list(range(len(names)))
+        assert hip_model.launch_plan(150) == list(range(len(names))) == hip_model.launch_plan(8)
         assert torch.equal(hip_model(x).cpu(), want)                                 # whole images, one block per launch
         assert torch.equal(hip_model(x[:60].contiguous()).cpu(), want[:60])          # 7-row bands
+        assert torch.equal(hip_model(x[:8].contiguous()).cpu(), want[:8])            # 2-row bands, one block per launch
     finally:
         hip_model.set_chain(True)
-    assert torch.equal(hip_model(x[:8].contiguous()).cpu(), want[:8])                # 2-row bands
+    assert torch.equal(hip_model(x[:8].contiguous()).cpu(), want[:8])                # 2-row bands, two blocks per launch
+    assert torch.equal(hip_model(x[:36].contiguous()).cpu(), want[:36])
+    assert torch.equal(hip_model(x[:1].contiguous()).cpu(), want[:1])
     assert hip_model.launch_plan(60)[first:first + 6] == [first] * 6
     assert torch.equal(hip_model(x[:60].contiguous()).cpu(), want[:60])              # one launch on a part-filled chip
 
