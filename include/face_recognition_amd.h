@@ -73,7 +73,8 @@ int mfn_set_fused(mfn_handle* h, int fused);
 
 /* chain != 0 (the default): a run of identical residual blocks (conv_4.model.0-5 and conv_5.model.0-1,
  * face_model.py:85-87) goes out as ONE launch that keeps the activation in registers between blocks, for batches
- * where whole-image workgroups fill the chip; 0: one launch per block.  Same results bit for bit either way. */
+ * where whole-image workgroups fill the chip, and conv_4's blocks go out two per launch for small batches (bands that
+ * compute their neighbours' nearest rows themselves); 0: one launch per block.  Same results bit for bit either way. */
 int mfn_set_chain(mfn_handle* h, int chain);
 /* first_op[i] (host, n_ops >= mfn_op_count entries) = the op whose launch covers op i in a batch of B images:
  * i itself, or the first block of the chain i runs in.  mfn_forward_timed books a chain's time on that op. */
@@ -145,8 +146,8 @@ int mfn_op_block(int dtype, int cin, int cexp, int cout, int h, int stride, int 
  * s1 / s2 [cexp]; out must hold mfn_rblock_package_bytes(c, cexp) bytes (0 = unsupported widths).
  * mfn_op_rblock runs nblk blocks whose packages lie back to back at `packages` (dev) on x -> out, both
  * T NHWC [B][h][h][c] (h = 14 or 7).  nblk > 1 keeps the activation in registers between blocks, and out may then
- * be x (a workgroup owns whole images); with nblk == 1 small batches run bands that read their neighbours' rows, so
- * out must not be x. */
+ * be x (a workgroup owns whole images; two blocks of a small batch of 14 x 14 maps run as bands when out is not x);
+ * with nblk == 1 small batches run bands that read their neighbours' rows, so out must not be x. */
 int64_t mfn_rblock_package_bytes(int c, int cexp);
 int mfn_pack_rblock(int dtype, int c, int cexp, const float* w1, const float* b1, const float* s1, const float* w2,
                     const float* b2, const float* s2, const float* w3, const float* b3, void* packages_host);
