@@ -201,7 +201,7 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
     static_assert(MTO == (STACK ? (GP * H + 1) / 2 : (TR + RPT - 1) / RPT), "tiles of whole rows");
     // halo tiles: tile MTO + j holds the rows y0 - 1 - j and y0 + TR + j (RPT == 1: a tile each for y0 - 1 and y0 + TR)
     constexpr int HT = WHOLE ? 0 : (RPT >= 2 ? CH : 2);
-    static_assert(CH == 1 || (!WHOLE && G == 1 && POW == 16 && RB_FLAGS), "several blocks per band launch: built for 14-wide maps");
+    static_assert(CH == 1 || (!WHOLE && G == 1 && RPT >= 2), "several blocks per band launch: halo rows share a tile");
     constexpr int MTI = MTO + HT;
     constexpr int KS = C / 32, NT16 = C / 16, NCH = CEXP / 64;
     constexpr int PITCH = STACK ? W + 1 : block_pitch<H, 1>(), SLOT = 144;
@@ -340,7 +340,11 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
         const int sub = SSPLIT ? en * ST1 : 0;                                 // (SSPLIT) this wave's subtile
         tb = ((CH - 1 + oy) * PITCH + ox + (g4 < 2 ? g4 : 2)) * SLOT + sub;
         // (CH > 1) the first halo tile as an OUTPUT tile: subtile 0 is row y0 - 1 (LDS row CH - 1), subtile 1 row y0 + TR
-        if (CH > 1 && wt == MTO) tb = ((CH - 2 + en * (TR + 1)) * PITCH + ox + (g4 < 2 ? g4 : 2)) * SLOT;
+        // (14-wide maps: a subtile is a row; 7-wide maps: subtile 0 holds both rows, 8 lanes each, subtile 1 no pixel)
+        if (CH > 1 && wt == MTO) {
+            const int below = POW == 16 ? en : (m16 >> 3);
+            tb = ((CH - 2 + below * (TR + 1)) * PITCH + ox + (g4 < 2 ? g4 : 2)) * SLOT;
+        }
         if constexpr (STACK) {                             // pixel slot less one row and one slot
             const int pr = 2 * wt + (m16 >> 3);
             tb = ((pr / H) * 64 + (pr % H) * PITCH + (m16 & 7) + (g4 < 2 ? g4 : 2)) * SLOT;
@@ -675,7 +679,9 @@ static int launch_rblock_t(int c, int cexp, int h, const void* x, const void* wp
     }
     if (c == 128 && cexp == 256 && h == 7) {
         int g = rb_stack_choice(B, cus);
-        if (nblk > 1 && g < 2) g = 2;                      // several blocks per launch: only the stacked shapes chain
+        // conv_5's two blocks as one launch of one-row bands (each band computes the rows above and below it itself)
+        if (g == 0 && nblk == 2 && x != out && rb_band_chain()) return launch_rblock_cfg<T, 128, 256, 7, 1, 8, 1, 2>(x, wp, 2, out, B, s);
+        if (nblk > 1 && g < 2) g = 2;                      // several blocks per launch otherwise: only the stacked shapes chain
         if (g == 0) return launch_rblock_cfg<T, 128, 256, 7, 1, 8>(x, wp, 1, out, B, s);
         if (g == 2) return launch_rblock_cfg<T, 128, 256, 7, 7, 5, 2>(x, wp, nblk, out, B, s);
         return launch_rblock_cfg<T, 128, 256, 7, 7, 8, 4>(x, wp, nblk, out, B, s);
@@ -687,7 +693,7 @@ static int launch_rblock_t(int c, int cexp, int h, const void* x, const void* wp
 int rblock_chain_blocks(int c, int cexp, int h, int B, int remaining) {
     if (remaining < 2) return 1;
     if (rblock_chain_pays(c, cexp, h, B)) return remaining;                 // whole images: the rest of the run in one launch
-    if (c == 128 && cexp == 256 && h == 14 && (int64_t)B * 7 <= rb_compute_units() && rb_band_chain()) return 2;
+    if (c == 128 && cexp == 256 && (h == 14 || h == 7) && (int64_t)B * 7 <= rb_compute_units() && rb_band_chain()) return 2;
     return 1;
 }
 

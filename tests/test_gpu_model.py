@@ -128,10 +128,12 @@ def test_chained_and_per_block_launches_agree_bit_for_bit(hip_model, device):
     first = names.index("conv_4.model.0")
     assert plan[first:first + 6] == [first] * 6                       # one launch covers the six blocks
     # small batch: conv_4 as three launches of two blocks each (two-row bands that compute their neighbours' nearest
-    # rows themselves), every other op a launch of its own
+    # rows themselves), conv_5 as one, every other op a launch of its own
     small = list(range(len(names)))
     for j in range(6):
         small[first + j] = first + 2 * (j // 2)
+    five = names.index("conv_5.model.0")
+    small[five + 1] = five                                            # conv_5's two blocks: one launch of one-row bands
     assert hip_model.launch_plan(8) == small
     hip_model.set_chain(False)
     try:
