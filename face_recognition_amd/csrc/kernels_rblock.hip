@@ -617,7 +617,9 @@ static int launch_rblock_cfg(const void* x, const void* wp, int nblk, void* out,
     FRA_REQUIRE(CH > 1 ? nblk == CH : (nblk == 1 || (TR == H && rb_main_tiles<H, TR, G>() > NW / 2)), FRA_ERR_ARG,
                 "rblock: %d blocks per launch need whole-image workgroups with a tile per wave", nblk);
     static_assert(G == 1 || rb_flags<H, TR, NW, G>(), "stacked images run on the flag-synchronised loop");
-    auto kern = CH > 1 ? rblock_kernel_w2<T, C, CEXP, H, TR, NW, G, CH> : rblock_kernel<T, C, CEXP, H, TR, NW, G, CH>;
+    void (*kern)(const T*, const char*, T*, int, int);
+    if constexpr (CH > 1) kern = rblock_kernel_w2<T, C, CEXP, H, TR, NW, G, CH>;
+    else kern = rblock_kernel<T, C, CEXP, H, TR, NW, G, CH>;
     static std::atomic<uint64_t> lds_set;      // per instantiation: devices whose LDS limit is raised
     static std::atomic<int> slots_of[64];      // resident workgroups per band, per device (0 = not asked yet)
     int dev = 0;
