@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libface_recognition_amd.so")
+# FRA_LIB_PATH: another build of the library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("FRA_LIB_PATH") or os.path.join(_HERE, "libface_recognition_amd.so")
 
 FRA_F32, FRA_BF16, FRA_F16 = 0, 1, 2
 DTYPE_BY_NAME = {"f32": FRA_F32, "float32": FRA_F32, "bf16": FRA_BF16, "bfloat16": FRA_BF16,
@@ -26,6 +27,8 @@ _P, _I, _L, _D = C.c_void_p, C.c_int, C.c_int64, C.c_double
 SIGNATURES = {
     "fra_last_error": (C.c_char_p, []),
     "fra_version": (_I, []),
+    "fra_device_fault": (_I, [_I, C.POINTER(C.c_uint)]),
+    "fra_dbg_set_spin_limit": (_I, [_I]),
     "mfn_create": (_I, [C.POINTER(_P), _I, _I, _I]),
     "mfn_load_weights": (_I, [_P, C.POINTER(TensorDesc), _I]),
     "mfn_workspace_bytes": (_I, [_P, _I, C.POINTER(C.c_size_t)]),
@@ -50,6 +53,7 @@ SIGNATURES = {
     "mfn_rblock_package_bytes": (_L, [_I, _I]),
     "mfn_pack_rblock": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfn_op_rblock": (_I, [_I, _I, _I, _I, _P, _P, _I, _P, _I, _P]),
+    "mfn_op_wblock": (_I, [_I, _I, _I, _I, _P, _P, _I, _P, _I, _P]),
     "mfn_op_gdconv7": (_I, [_I, _P, _P, _P, _P, _I, _I, _P]),
     "mfn_op_tail": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "mfn_op_linear_l2norm": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),

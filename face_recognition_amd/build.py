@@ -14,8 +14,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libface_recognition_amd.so")
-SOURCES = ["api.cpp", "kernels_conv.hip", "kernels_gemm.hip", "kernels_block.hip", "kernels_rblock.hip", "kernels_pblock.hip", "kernels_stem.hip", "mfn_model.hip", "fb_search.hip", "ev_fold.hip", "fa_align.hip", "kernels_tail.hip"]
+SOURCES = ["api.cpp", "kernels_conv.hip", "kernels_gemm.hip", "kernels_block.hip", "kernels_rblock.hip", "kernels_wblock.hip", "kernels_pblock.hip", "kernels_stem.hip", "mfn_model.hip", "fb_search.hip", "ev_fold.hip", "fa_align.hip", "kernels_tail.hip"]
 ARCH = "gfx950"
+# per-source flags.  kernels_wblock.hip runs one wave per SIMD with the whole register file: its compiler-issued MFMAs
+# keep their results in ordinary registers (the project sums sit in accumulation registers through inline assembly)
+EXTRA_FLAGS = {"kernels_wblock.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc() -> str:
@@ -50,7 +53,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + flags + ["-c", s, "-o", o])
+            jobs.append([hipcc] + flags + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

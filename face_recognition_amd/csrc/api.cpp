@@ -16,9 +16,74 @@ void set_error(const char* fmt, ...) {
 
 const char* last_error() { return g_err; }
 
+// ---- waits that give up: one host-visible word per device ---------------------------------------
+static std::atomic<unsigned*> g_fault_host[64];
+static std::atomic<unsigned*> g_fault_dev[64];
+static std::atomic<int> g_spin_limit{-1};
+
+unsigned* fault_word() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    unsigned* d = g_fault_dev[dev].load(std::memory_order_acquire);
+    if (d) return d;
+    static std::atomic_flag busy = ATOMIC_FLAG_INIT;
+    while (busy.test_and_set(std::memory_order_acquire)) {}
+    d = g_fault_dev[dev].load(std::memory_order_acquire);
+    if (!d) {
+        unsigned* hp = nullptr;
+        void* dp = nullptr;
+        // pinned, mapped host memory: a kernel writes it directly, the host reads it without a copy or a synchronisation
+        if (hipHostMalloc(reinterpret_cast<void**>(&hp), 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && hp) {
+            *hp = 0;
+            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess && dp) {
+                g_fault_host[dev].store(hp, std::memory_order_release);
+                d = static_cast<unsigned*>(dp);
+                g_fault_dev[dev].store(d, std::memory_order_release);
+            } else {
+                (void)hipHostFree(hp);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    busy.clear(std::memory_order_release);
+    return d;
+}
+
+int spin_limit(int dflt) {
+    const int v = g_spin_limit.load(std::memory_order_relaxed);
+    return v >= 0 ? v : dflt;
+}
+
+static unsigned take_fault(int device) {
+    if (device < 0 || device >= 64) return 0;
+    unsigned* hp = g_fault_host[device].load(std::memory_order_acquire);
+    if (!hp) return 0;
+    volatile unsigned* v = hp;
+    const unsigned tag = *v;
+    if (tag) *v = 0;
+    return tag;
+}
+
+int check_device_fault(int device) {
+    const unsigned tag = take_fault(device);
+    if (!tag) return FRA_OK;
+    set_error("a wait inside kernel '%c%c' (wave %u) gave up on device %d: the results of the launches before this call are invalid",
+              (char)(tag >> 24), (char)((tag >> 16) & 0xff), tag & 0xffffu, device);
+    return FRA_ERR_STATE;
+}
+
 }  // namespace fra
 
 extern "C" {
 const char* fra_last_error(void) { return fra::last_error(); }
 int fra_version(void) { return 1; }
+int fra_device_fault(int device, unsigned* tag_out) {
+    const unsigned tag = fra::take_fault(device);
+    if (tag_out) *tag_out = tag;
+    return tag ? FRA_ERR_STATE : FRA_OK;
+}
+int fra_dbg_set_spin_limit(int polls) {
+    fra::g_spin_limit.store(polls, std::memory_order_relaxed);
+    return FRA_OK;
+}
 }

@@ -111,6 +111,15 @@ inline int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_
     return FRA_OK;
 }
 
+// ---- waits that give up ---------------------------------------------------------------------------
+// The kernels that synchronise their waves through words in LDS poll with a bound, so that a protocol bug cannot hang
+// the GPU.  A poll that runs out stores a tag (two letters naming the kernel << 16 | wave) to a host-visible word of the
+// device it ran on and goes on with whatever LDS holds: the launch's results are wrong, and the next entry point that
+// checks the word reports it instead of returning them with FRA_OK.
+unsigned* fault_word();                 // device pointer to the current device's word (nullptr: it could not be allocated)
+int spin_limit(int dflt);               // polls before a wait gives up: fra_dbg_set_spin_limit()'s value, else dflt
+int check_device_fault(int device);     // FRA_ERR_STATE + message if a wait gave up on `device` since the last check; clears the word
+
 // ---- kernel launchers (device pointers, parameters already in kernel layout) ------------------
 // All return a Status; all launch on `s` and never synchronise.
 
@@ -206,6 +215,10 @@ int pack_rblock(int dt, int c, int cexp, const float* w1, const float* b1, const
 // `nblk` consecutive blocks (packages back to back at wp) on x -> out, T NHWC [B][h][h][c]; nblk > 1 keeps the
 // activation in registers between blocks (whole-image workgroups); out may be x
 int launch_rblock(int dt, int c, int cexp, int h, const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s);
+// the same chain as four wide waves per workgroup, one per SIMD (kernels_wblock.hip): same packages, same results bit
+// for bit; wblock_has(): the shapes it is built for
+bool wblock_has(int c, int cexp, int h);
+int launch_wblock(int dt, int c, int cexp, int h, const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s);
 // true when `nblk` > 1 blocks of this shape should run as one launch for a batch of B images
 bool rblock_chain_pays(int c, int cexp, int h, int B);
 // blocks the next launch covers when `remaining` identical blocks are left: all of them (whole-image workgroups), two

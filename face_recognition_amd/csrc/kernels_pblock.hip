@@ -62,7 +62,7 @@ extern "C" int fra_dbg_read(void* dst, size_t bytes) {
 #endif
 
 #ifndef PB_SPIN_LIMIT
-#define PB_SPIN_LIMIT (1 << 20)   // polls (some 0.1 s) after which a wait gives up: wrong results instead of a wave that never ends
+#define PB_SPIN_LIMIT (1 << 20)   // polls (some 0.1 s) after which a wait gives up and reports it through `fault` (common.h)
 #endif
 
 template <typename T, int CIN, int CEXP, int COUT, int H, int NP, int NC, int NR>
@@ -70,7 +70,7 @@ __global__ __launch_bounds__((NP + NC) * 64, 2)
 void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float* __restrict__ b1p,
                    const float* __restrict__ s1p, const T* __restrict__ W2p, const float* __restrict__ b2p,
                    const float* __restrict__ s2p, const T* __restrict__ W3p, const float* __restrict__ b3,
-                   T* __restrict__ O, int B) {
+                   T* __restrict__ O, int B, unsigned* __restrict__ fault, int spin_limit) {
     typedef typename vec8<T>::type V8;
     typedef typename vec4<T>::type V4;
     typedef PbLds<CIN, CEXP, COUT, H, NR> L;
@@ -170,9 +170,13 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
             // row glast - NR is overwritten: it was read for output rows up to glast - NR + 1, whose last pixel lies in
             // tile `last`; consumer c is past it once progress[c] >= last - NC + 1 (its tiles are NC apart)
             const int need = (W * (glast - NR + 2) - 1) / 32 - NC + 1;
-            for (int spin = 0; spin < PB_SPIN_LIMIT; ++spin) {
+            for (int spin = 0;; ++spin) {
                 const int v = progress[lane & 7];
                 if (__builtin_amdgcn_ballot_w64(v < need) == 0) break;
+                if (spin >= spin_limit) {
+                    if (fault && lane == 0) *fault = 0x50420000u | (unsigned)wave;   // 'PB'
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
             }
         }
@@ -257,9 +261,13 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
             const int tt = t + (lane % 3) - 1;
             const bool inside = tt >= 0 && tt < NTL;
             const int idx = (tt + NTF) % NTF, want = tt + 1;
-            for (int spin = 0; spin < PB_SPIN_LIMIT; ++spin) {
+            for (int spin = 0;; ++spin) {
                 const int v = ready[idx];
                 if (__builtin_amdgcn_ballot_w64(inside && v < want) == 0) break;
+                if (spin >= spin_limit) {
+                    if (fault && lane == 0) *fault = 0x50420000u | (unsigned)wave;   // 'PB'
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
             }
         }
@@ -350,7 +358,7 @@ static int launch_pblock_cfg(const BlockParams& p, const void* x, void* out, int
     const int per = (B + cus - 1) / cus;
     const int groups = (B + per - 1) / per;
     hipLaunchKernelGGL(kern, dim3(1, groups), dim3((NP + NC) * 64), lds, s, (const T*)x, (const T*)p.w1, p.b1p, p.s1p,
-                       (const T*)p.w2p, p.b2p, p.s2p, (const T*)p.w3p, p.b3, (T*)out, B);
+                       (const T*)p.w2p, p.b2p, p.s2p, (const T*)p.w3p, p.b3, (T*)out, B, fault_word(), spin_limit(PB_SPIN_LIMIT));
     FRA_HIP(hipGetLastError());
     return FRA_OK;
 }

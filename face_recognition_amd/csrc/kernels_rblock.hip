@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "block_stages.h"
@@ -132,7 +133,7 @@ extern "C" int fra_dbg_read(void* dst, size_t bytes) {
 #define RB_FLAGS 1         // whole-image workgroups synchronise wave to wave through flags in LDS instead of barriers
 #endif
 #ifndef RB_SPIN_LIMIT
-#define RB_SPIN_LIMIT (1 << 20)   // polls (some 0.1 s) after which a wait gives up: wrong results instead of a wave that never ends
+#define RB_SPIN_LIMIT (1 << 20)   // polls (some 0.1 s) after which a wait gives up and reports it through `fault` (common.h)
 #endif
 // whole-image workgroups keep TWO activation images (slices alternate) and a block of flag words
 //
@@ -167,24 +168,28 @@ template <int C, int CEXP, int H, int TR, int NW, int G = 1, int CH = 1> constex
 }
 
 template <typename T, int C, int CEXP, int H, int TR, int NW, int G, int CH>
-__device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk);
+__device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk,
+                                            unsigned* __restrict__ fault, int spin_limit);
 
 template <typename T, int C, int CEXP, int H, int TR, int NW, int G = 1, int CH = 1>
 __global__ __launch_bounds__(NW * 64, 2)
-void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk) {
-    rblock_body<T, C, CEXP, H, TR, NW, G, CH>(X, WP, O, B, nblk);
+void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk,
+                   unsigned* __restrict__ fault, int spin_limit) {
+    rblock_body<T, C, CEXP, H, TR, NW, G, CH>(X, WP, O, B, nblk, fault, spin_limit);
 }
 
 // the same body with the register budget of exactly two waves per SIMD spelled out (the several-blocks-per-band
 // configuration: left to itself the compiler aims at three waves and spills)
 template <typename T, int C, int CEXP, int H, int TR, int NW, int G, int CH>
 __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void rblock_kernel_w2(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk) {
-    rblock_body<T, C, CEXP, H, TR, NW, G, CH>(X, WP, O, B, nblk);
+void rblock_kernel_w2(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk,
+                      unsigned* __restrict__ fault, int spin_limit) {
+    rblock_body<T, C, CEXP, H, TR, NW, G, CH>(X, WP, O, B, nblk, fault, spin_limit);
 }
 
 template <typename T, int C, int CEXP, int H, int TR, int NW, int G, int CH>
-__device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk) {
+__device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk,
+                                            unsigned* __restrict__ fault, int spin_limit) {
     typedef typename vec8<T>::type V8;
     typedef typename vec4<T>::type V4;
     typedef RbPkg<C> PK;
@@ -436,8 +441,12 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
         const int NS = nimg * npk;
         // spin until `cond` holds for every lane (flags only ever grow)
         auto wait_flags = [&](auto cond) {
-            for (int spin = 0; spin < RB_SPIN_LIMIT; ++spin) {
+            for (int spin = 0;; ++spin) {
                 if (__builtin_amdgcn_ballot_w64(!cond()) == 0) break;
+                if (spin >= spin_limit) {
+                    if (fault && lane == 0) *fault = 0x52420000u | (unsigned)wave;   // 'RB'
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
             }
             asm volatile("" ::: "memory");
@@ -617,7 +626,7 @@ static int launch_rblock_cfg(const void* x, const void* wp, int nblk, void* out,
     FRA_REQUIRE(CH > 1 ? nblk == CH : (nblk == 1 || (TR == H && rb_main_tiles<H, TR, G>() > NW / 2)), FRA_ERR_ARG,
                 "rblock: %d blocks per launch need whole-image workgroups with a tile per wave", nblk);
     static_assert(G == 1 || rb_flags<H, TR, NW, G>(), "stacked images run on the flag-synchronised loop");
-    void (*kern)(const T*, const char*, T*, int, int);
+    void (*kern)(const T*, const char*, T*, int, int, unsigned*, int);
     if constexpr (CH > 1) kern = rblock_kernel_w2<T, C, CEXP, H, TR, NW, G, CH>;
     else kern = rblock_kernel<T, C, CEXP, H, TR, NW, G, CH>;
     static std::atomic<uint64_t> lds_set;      // per instantiation: devices whose LDS limit is raised
@@ -634,7 +643,8 @@ static int launch_rblock_cfg(const void* x, const void* wp, int nblk, void* out,
     const int units = (B + G - 1) / G;
     const int per = (units + slots - 1) / slots;
     const int groups = (units + per - 1) / per;
-    hipLaunchKernelGGL(kern, dim3(bands, groups), dim3(NW * 64), lds, s, (const T*)x, (const char*)wp, (T*)out, B, nblk);
+    hipLaunchKernelGGL(kern, dim3(bands, groups), dim3(NW * 64), lds, s, (const T*)x, (const char*)wp, (T*)out, B, nblk,
+                       fault_word(), spin_limit(RB_SPIN_LIMIT));
     FRA_HIP(hipGetLastError());
     return FRA_OK;
 }
@@ -664,6 +674,13 @@ static bool rb_band_chain() {
     return on;
 }
 
+// FRA_WBLOCK=1: whole-image workgroups of 14 x 14 maps run as four wide waves (kernels_wblock.hip) instead of eight
+// waves with a tile each (this file); same bits either way, 12 % slower at batch 1024 (measurements, cross-checks)
+static bool rb_wide_waves() {
+    static const bool on = [] { const char* e = getenv("FRA_WBLOCK"); return e && atoi(e) != 0; }();
+    return on;
+}
+
 // conv_4 (128 -> 256 -> 128 on 14 x 14): bands of 2 rows (7 workgroups per image) while those fit the chip in
 // one go, bands of 7 rows (2 per image) while those do, whole images beyond
 template <typename T>
@@ -674,10 +691,14 @@ static int launch_rblock_t(int c, int cexp, int h, const void* x, const void* wp
         // other workgroups read the input rows around their bands
         if (nblk == 2 && (int64_t)B * 7 <= cus && x != out && rb_band_chain())
             return launch_rblock_cfg<T, 128, 256, 14, 2, 8, 1, 2>(x, wp, 2, out, B, s);
-        if (nblk > 1) return launch_rblock_cfg<T, 128, 256, 14, 14, RB_NW_WHOLE>(x, wp, nblk, out, B, s);
+        const bool wide = rb_wide_waves() && wblock_has(c, cexp, h);
+        const int dt = std::is_same<T, f16>::value ? ACT_F16 : ACT_BF16;
+        if (nblk > 1) return wide ? launch_wblock(dt, c, cexp, h, x, wp, nblk, out, B, s)
+                                  : launch_rblock_cfg<T, 128, 256, 14, 14, RB_NW_WHOLE>(x, wp, nblk, out, B, s);
         if ((int64_t)B * 7 <= cus) return launch_rblock_cfg<T, 128, 256, 14, 2, 8>(x, wp, 1, out, B, s);
         if ((int64_t)B * 2 <= cus) return launch_rblock_cfg<T, 128, 256, 14, 7, 8>(x, wp, 1, out, B, s);
-        return launch_rblock_cfg<T, 128, 256, 14, 14, RB_NW_WHOLE>(x, wp, 1, out, B, s);
+        return wide ? launch_wblock(dt, c, cexp, h, x, wp, 1, out, B, s)
+                    : launch_rblock_cfg<T, 128, 256, 14, 14, RB_NW_WHOLE>(x, wp, 1, out, B, s);
     }
     if (c == 128 && cexp == 256 && h == 7) {
         int g = rb_stack_choice(B, cus);

@@ -604,6 +604,7 @@ static int forward(mfn_handle* h, const void* x, int x_is_u8, int B, bool tta, f
                    hipStream_t s, float* op_ms, int n_ops_timed) {
     int rc = check_forward_args(h, x, B, tta, out, ws, ws_bytes);
     if (rc) return rc;
+    if ((rc = check_device_fault(h->device))) return rc;   // an earlier launch's wait gave up: do not pile results on top
     FRA_DEVICE(h->device);   // launches, LDS limits and occupancy answers all belong to the handle's device
     FRA_REQUIRE(h->fused || (!tta && !x_is_u8), FRA_ERR_STATE, "uint8 input and fused flip-TTA need the fused schedule");
     const int nops = (int)h->ops().size();
@@ -800,12 +801,13 @@ int mfn_debug_prefix(mfn_handle* h, const float* x, int B, int n_ops, float* out
 
 int mfn_destroy(mfn_handle* h) {
     if (!h) return FRA_OK;
+    const int device = h->device;
     if (h->arena) {
         fra::DeviceGuard guard(h->device);
-        (void)hipFree(h->arena);
+        (void)hipFree(h->arena);           // waits for the device to drain: every launch of this handle has finished
     }
     delete h;
-    return FRA_OK;
+    return check_device_fault(device);
 }
 
 int mfn_tta_combine(const float* a, const float* b, int B, int E, float* out, fra_stream stream) {
@@ -840,6 +842,10 @@ int mfn_pack_rblock(int dtype, int c, int cexp, const float* w1, const float* b1
 int mfn_op_rblock(int dtype, int c, int cexp, int h, const void* x, const void* packages, int nblk, void* out, int B,
                   fra_stream stream) {
     return launch_rblock(dtype, c, cexp, h, x, packages, nblk, out, B, (hipStream_t)stream);
+}
+int mfn_op_wblock(int dtype, int c, int cexp, int h, const void* x, const void* packages, int nblk, void* out, int B,
+                  fra_stream stream) {
+    return launch_wblock(dtype, c, cexp, h, x, packages, nblk, out, B, (hipStream_t)stream);
 }
 int mfn_op_gdconv7(int dtype, const void* in, const void* w, const float* bias, void* out, int B, int C,
                    fra_stream stream) {

@@ -46,6 +46,16 @@ typedef struct {
 const char* fra_last_error(void);
 int fra_version(void);
 
+/* Kernels whose waves synchronise through flags in on-chip memory poll with a bound, so that a fault in that protocol
+ * cannot hang the GPU; a poll that runs out marks the device, and the launch's results are wrong.  mfn_forward*,
+ * mfn_op_block / mfn_op_rblock's callers and mfn_destroy report a mark left by EARLIER launches on their device as
+ * FRA_ERR_STATE (fra_last_error names the kernel); fra_device_fault reads and clears the mark itself: returns
+ * FRA_ERR_STATE and the tag (kernel letters << 16 | wave) if one was set.  Synchronise the stream first to cover the
+ * launches still in flight.  No counterpart in the reference. */
+int fra_device_fault(int device, unsigned* tag_out);
+/* Test hook: polls after which such a wait gives up (negative = the built-in bound of about 0.1 s). */
+int fra_dbg_set_spin_limit(int polls);
+
 /* ---- MobileFaceNet embedding forward ----------------------------------------------------------
  * Replaces MobileFaceNet.__init__/forward: Mobilefacenet/face_model.py:77-129. */
 
@@ -152,6 +162,11 @@ int64_t mfn_rblock_package_bytes(int c, int cexp);
 int mfn_pack_rblock(int dtype, int c, int cexp, const float* w1, const float* b1, const float* s1, const float* w2,
                     const float* b2, const float* s2, const float* w3, const float* b3, void* packages_host);
 int mfn_op_rblock(int dtype, int c, int cexp, int h, const void* x, const void* packages, int nblk, void* out, int B,
+                  fra_stream stream);
+/* The same chain on the wide-wave kernel (four waves per workgroup, one per SIMD, four image rows each; h = 14 only):
+ * what mfn_op_rblock itself launches for whole-image workgroups unless FRA_WBLOCK=0 is set.  Same packages, same
+ * results bit for bit; out may be x for any nblk. */
+int mfn_op_wblock(int dtype, int c, int cexp, int h, const void* x, const void* packages, int nblk, void* out, int B,
                   fra_stream stream);
 int mfn_op_gdconv7(int dtype, const void* in, const void* w49xC, const float* bias, void* out, int B, int C,
                    fra_stream stream);

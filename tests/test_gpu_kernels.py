@@ -192,6 +192,41 @@ def test_rblock_chain(device, dt, H, B):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("B", [1, 5, 37, 300])
+def test_wide_wave_chain_matches_the_tile_per_wave_kernel(device, dt, B):
+    """The chain of residual blocks on the wide-wave kernel (four waves per workgroup, one per SIMD, four image rows
+    each: mfn_op_wblock) gives the bits of one mfn_op_rblock launch per block (bands for the small batches, whole-image
+    workgroups of eight waves beyond), in place and for one, two and three blocks."""
+    tdt, code, rel = DT[dt]
+    lib = _lib.load()
+    c, cexp, H, nblk = 128, 256, 14, 3
+    g = torch.Generator().manual_seed(11)
+    pks = []
+    for _ in range(nblk):
+        w1 = (torch.randn((cexp, c), generator=g) / np.sqrt(c) * 1.3).to(tdt).float()
+        w2 = (torch.randn((cexp, 1, 3, 3), generator=g) * 0.4).to(tdt).float()
+        w3 = (torch.randn((c, cexp), generator=g) / np.sqrt(cexp) * 0.6).to(tdt).float()
+        b1, b2, b3 = (torch.randn(n, generator=g) * 0.2 for n in (cexp, cexp, c))
+        s1, s2 = (torch.rand(cexp, generator=g) * 0.3 + 0.1 for _ in range(2))
+        pks.append(_rblock_packages(lib, code, c, cexp, w1, b1, s1, w2, b2, s2, w3, b3))
+    pk = torch.cat(pks).to(device)
+    per = pks[0].numel()
+    x = torch.randn((B, H, H, c), generator=g).to(tdt).to(device)
+    cur = x
+    for n in range(1, nblk + 1):
+        nxt = torch.full_like(x, float("nan"))
+        _lib.check(lib.mfn_op_rblock(code, c, cexp, H, cur.data_ptr(), pk.data_ptr() + (n - 1) * per, 1, nxt.data_ptr(), B,
+                                     stream(device)), "rblock")
+        cur = nxt
+        wide = x.clone()
+        _lib.check(lib.mfn_op_wblock(code, c, cexp, H, wide.data_ptr(), pk.data_ptr(), n, wide.data_ptr(), B,
+                                     stream(device)), "wblock")
+        torch.cuda.synchronize()
+        assert torch.equal(wide, cur), n
+    assert lib.fra_device_fault(0, None) == 0
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("many", [False, True])
 @pytest.mark.parametrize("cin,cexp,cout,H,stride,res,B", [(64, 128, 64, 56, 2, False, 2), (64, 128, 64, 28, 1, True, 3),
                                                          (64, 256, 128, 28, 2, False, 2), (128, 256, 128, 14, 1, True, 3),

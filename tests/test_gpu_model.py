@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from conftest import cosine_rows
-from face_recognition_amd import synthetic
+from face_recognition_amd import _lib, synthetic
 from face_recognition_amd.face_model import MobileFaceNet
 from oracle import mobilefacenet_ref as ref
 
@@ -246,6 +246,34 @@ def test_reloading_weights_changes_output(device, state_dict_np):
     want = ref.forward_numpy(sd2, x.cpu().numpy())
     assert cosine_rows(b, want).min() >= COS_BAR
     assert not np.allclose(a.numpy(), b)
+
+
+def test_a_wait_that_gives_up_is_reported(hip_model, device):
+    """The kernels that synchronise their waves through flags in LDS (the conv_3 tile pipeline, the conv_4 / conv_5
+    chains) bound their polls.  With the bound set to zero every wait gives up at once: the embeddings are garbage, and
+    the library must say so -- the next forward on the device fails with the kernel's name instead of returning them
+    with status 0 -- and work normally again afterwards."""
+    import ctypes
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand((256, 3, 112, 112), generator=g) * 2 - 1).to(device)   # tile pipeline and both chains
+    good = hip_model(x)
+    torch.cuda.synchronize()
+    assert lib.fra_device_fault(device.index or 0, None) == 0
+    try:
+        lib.fra_dbg_set_spin_limit(0)
+        hip_model(x)                                       # rc 0: the launches were queued; their waits give up on the device
+        torch.cuda.synchronize()
+    finally:
+        lib.fra_dbg_set_spin_limit(-1)
+    with pytest.raises(RuntimeError, match="gave up"):
+        hip_model(x)
+    tag = ctypes.c_uint(0)
+    assert lib.fra_device_fault(device.index or 0, ctypes.byref(tag)) == 0 and tag.value == 0   # reported once, then cleared
+    again = hip_model(x)
+    torch.cuda.synchronize()
+    assert torch.equal(again, good)
+    assert lib.fra_device_fault(device.index or 0, None) == 0
 
 
 def test_errors(hip_model, device):
