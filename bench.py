@@ -104,6 +104,46 @@ def per_kernel_profile(net, x, reps, dt):
     return groups, float(ms.sum())
 
 
+MAX_CLOCK_GHZ = 2.4       # MI355X shader clock ceiling; kernels with matrix work hold 1.9 to 2.2 GHz
+
+
+def incu_bounds(groups, B):
+    """The in-CU floor of every kernel beside its two rooflines.  profiles/r*_incu.json (scripts/gpu_incu.sh +
+    scripts/incu_profile.py, batch 1024) holds, per kernel and launch, the clocks its executed instructions need on the
+    matrix pipe (per SIMD), the LDS array (per compute unit) and the vector ALU (per SIMD); the largest of the three at
+    the chip's clock ceiling is a time no schedule of THOSE instructions can beat, and `frac` = that floor / this run's
+    launch time says how close the kernel is to it.  `frac_at_profiled_clock` divides by the kernel's own clocks in the
+    profiled run instead (the clock the chip really held).  Returns ({kernel label: dict}, source file)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_incu.json")), reverse=True):
+        try:
+            with open(path) as f:
+                prof = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if prof.get("batch") != B:
+            continue
+        out = {}
+        for label, v in groups.items():
+            key = "void fra::" + label[:-1]
+            hit = [k for k in prof["kernels"] if k.startswith(key + ",") or k.startswith(key + ">")]
+            if len(hit) != 1 or not v["launches"]:
+                out[label] = None
+                continue
+            p = prof["kernels"][hit[0]]
+            m, busy = p["model_clocks_per_launch"], p["counter_busy_clocks_per_launch"]
+            us = {k.replace("_clocks", "_us"): round(c / (MAX_CLOCK_GHZ * 1e3), 2) for k, c in m.items()}
+            top = max(m, key=m.get)
+            launch_us = v["ms"] / v["launches"] * 1e3
+            hbm_us = v["bytes"] / v["launches"] / (HBM_PEAK_GBS * 1e9) * 1e6
+            out[label] = dict(us, bound=top.replace("_clocks", ""), floor_us=us[top.replace("_clocks", "_us")],
+                              launch_us=round(launch_us, 2), frac=round(us[top.replace("_clocks", "_us")] / launch_us, 4),
+                              frac_at_profiled_clock=round(m[top] / busy["kernel_clocks"], 4) if busy.get("kernel_clocks") else None,
+                              hbm_floor_us=round(hbm_us, 2), above_hbm_floor=bool(us[top.replace("_clocks", "_us")] > hbm_us))
+        return out, os.path.relpath(path, ROOT)
+    return {label: None for label in groups}, None
+
+
 def roofline_by_class(groups, B):
     """The two layer classes the forward is judged on, from the per-kernel event times.  Depthwise and pointwise
     convs run FUSED in the block kernels (and conv_6_sep + GDConv in the tail kernel), so both classes are carried by
@@ -215,7 +255,7 @@ def sampled_bruteforce(q, gal_chunks, total, k, sample, dev):
 
 def run_search(args, rank, world, dev, dist_mod, total=None, check_sample=0):
     from face_recognition_amd.facebank import Gallery
-    from face_recognition_amd.sharded import ShardedGallery, shard_bounds
+    from face_recognition_amd.sharded import ShardedGallery, result_digest, shard_bounds
     total = args.gallery_rows if total is None else total
     b, e = shard_bounds(total, world, rank)
     gal = Gallery(None, n=e - b, d=512, store="f16", device=dev, index_base=b)
@@ -271,15 +311,73 @@ def run_search(args, rank, world, dev, dist_mod, total=None, check_sample=0):
         dist_mod.all_reduce(el, op=dist_mod.ReduceOp.MAX)
     el = float(el) / args.search_steps
     flops = 2.0 * 512 * Q * total
+    # the three steps apart (a synchronisation after each, so their sum exceeds ms_per_batch), slowest rank per step
+    parts = None
+    for _ in range(2):
+        d, i, parts = sg.search_timed(q, 5)
+    pt = torch.tensor([parts["local_search_ms"], parts["allgather_ms"], parts["merge_ms"]], dtype=torch.float64,
+                      device=dev if world == 1 or dist_mod.get_backend() == "nccl" else "cpu")
+    if world > 1:
+        dist_mod.all_reduce(pt, op=dist_mod.ReduceOp.MAX)
+    shard = {"rows_per_gpu": e - b, "local_search_ms": round(float(pt[0]), 3), "allgather_ms": round(float(pt[1]), 3),
+             "merge_ms": round(float(pt[2]), 3), "lists_merged": world,
+             "allgather_bytes_received_per_rank": (world - 1) * Q * 5 * 8}
+    digest = result_digest(i)
     gal.close()
     return {"metric": "1:N top-5 queries/sec", "value": round(Q / el, 1), "unit": "queries/s", "queries": Q,
             "gallery_rows": total, "rows_per_gpu": e - b, "k": 5, "gallery_dtype": "f16", "ms_per_batch": round(el * 1e3, 3),
             "scaling": "strong", "planted_top1_hit_rate": round(hit, 5), "bruteforce_check": check,
+            # SHA-256 of the [Q,5] int32 index tensor (16 hex digits): the same gallery and queries give the same digest
+            # at every world size, so an N-GPU run is checked against the 1-GPU run by comparing this string
+            "result_digest": digest, "shard": shard,
             "gallery_build_s": round(build_s, 2),
             "merge": (("RCCL" if dist_mod.get_backend() == "nccl" else dist_mod.get_backend()) + " all_gather + fb_merge_topk") if world > 1 else "none (1 shard)",
             "roofline": {"bound": "mfma", "achieved": round(flops / el / 1e12, 2), "peak": MFMA_PEAK_TFLOPS * world,
                          "unit": "TFLOP/s", "frac": round(flops / el / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
                          "traffic": None}}
+
+
+def shard_rehearsal(args, dev, shards=8):
+    """What ONE rank of an `shards`-GPU run of the sharded search does, timed on this GPU: the search of shard 0 (rows
+    [0, total / shards) of the same logical gallery, same queries) and the merge of `shards` candidate lists.  The
+    all-gather between them cannot be measured on one GPU: (shards - 1) * Q * 5 * 8 bytes arrive per rank over xGMI
+    (2.8 MB at 8 ranks and 10k queries; some 20 us at 153 GB/s per link) -- 0.05 ms is assumed for it."""
+    from face_recognition_amd.facebank import Gallery, merge_topk
+    from face_recognition_amd.sharded import shard_bounds
+    total, Q = args.gallery_rows, args.queries
+    b, e = shard_bounds(total, shards, 0)
+    gal = Gallery(None, n=e - b, d=512, store="f16", device=dev, index_base=b)
+    for c in range(b // CHUNK_ROWS, (e - 1) // CHUNK_ROWS + 1):
+        rows = gallery_chunk(c, dev)
+        lo, hi = max(b, c * CHUNK_ROWS), min(e, (c + 1) * CHUNK_ROWS)
+        gal.fill(lo - b, rows[lo - c * CHUNK_ROWS: hi - c * CHUNK_ROWS])
+    del rows
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    q = torch.randn((Q, 512), generator=g, device=dev)
+    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    d, i = gal.search(q, 5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.search_steps):
+        d, i = gal.search(q, 5)
+    torch.cuda.synchronize()
+    local_ms = (time.perf_counter() - t0) / args.search_steps * 1e3
+    # `shards` lists per query: this shard's own and copies of it with the indices of the other shards' rows
+    gd = torch.stack([d + 1e-3 * r for r in range(shards)])
+    gi = torch.stack([i + r * (e - b) for r in range(shards)]).to(torch.int32)
+    merge_topk(gd, gi, 5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        md, mi = merge_topk(gd, gi, 5)
+    torch.cuda.synchronize()
+    merge_ms = (time.perf_counter() - t0) / 20 * 1e3
+    assert torch.equal(mi.to(torch.int64), i.to(torch.int64))          # the unshifted list wins every slot
+    gal.close()
+    assumed = 0.05
+    return {"shards": shards, "rows_per_gpu": e - b, "local_search_ms": round(local_ms, 3), "merge_ms": round(merge_ms, 3),
+            "allgather_assumed_ms": assumed, "predicted_ms": round(local_ms + merge_ms + assumed, 3)}
 
 
 def latency(net, dev):
@@ -520,9 +618,16 @@ def main():
                               "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                               "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                               "share_of_forward": round(dom["ms"] / total_ms, 3)}
+        incu, incu_source = incu_bounds(groups, B)
         result["kernels"] = {k: {"kind": v["kind"], "launches": v["launches"], "ms": round(v["ms"], 4),
                                  "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
-                                 "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in groups.items()}
+                                 "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                 "incu": incu[k]} for k, v in groups.items()}
+        # the executed-instruction counts behind `incu` come from a committed profile (like roofline.traffic), the launch
+        # times from this run; null where no profile of this batch size knows the kernel
+        result["incu_source"] = incu_source
+        if incu.get(dom_name):
+            result["roofline"]["incu"] = incu[dom_name]
         result["sum_kernel_ms"] = round(total_ms, 4)
         result["roofline_by_class"] = roofline_by_class(groups, B)
         if not args.no_latency:
@@ -536,6 +641,11 @@ def main():
             result["search_1m"] = run_search(args, rank, world, dev, dist, total=1_000_000, check_sample=40)
         # the full-size gallery: every 500th query (10 planted, 10 random) against the fp32 brute force over all rows
         s = run_search(args, rank, world, dev, dist, check_sample=500)
+        if world == 1 and args.gallery_rows >= 8 * CHUNK_ROWS:
+            # one rank's share of the 8-GPU run, timed here: what the 1 -> 8 GPU scaling of this search should come to
+            s["predicted_8gpu"] = shard_rehearsal(args, dev, 8)
+            s["predicted_8gpu_ms"] = s["predicted_8gpu"]["predicted_ms"]
+            s["predicted_scaling_1_to_8"] = round(s["ms_per_batch"] / s["predicted_8gpu_ms"], 2)
         if rank == 0:
             result["search"] = s
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -16,7 +16,9 @@ exercised with the gloo backend on hosts without a GPU; by default they are the 
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+import hashlib
+import time
+from typing import Callable, Dict, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -29,6 +31,14 @@ def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
     base, extra = divmod(total, world)
     start = rank * base + min(rank, extra)
     return start, start + base + (1 if rank < extra else 0)
+
+
+def result_digest(idx: torch.Tensor) -> str:
+    """Digest of a search result's index tensor [Q,k] (row-major int32 bytes, first 16 hex digits of their SHA-256).
+    The sharded search returns the same indices for any number of shards (ties go to the lowest global index in the
+    shard search and in the merge alike), so runs at different world sizes must print the same digest."""
+    a = idx.detach().to("cpu", torch.int32).contiguous().numpy()
+    return hashlib.sha256(a.tobytes()).hexdigest()[:16]
 
 
 def _hip_merge(dist_parts: torch.Tensor, idx_parts: torch.Tensor, k: int):
@@ -100,6 +110,28 @@ class ShardedGallery:
             return ld, li
         gd, gi = allgather_topk(ld, li, self.group)
         return self.merge(gd, gi, k)
+
+
+    def search_timed(self, queries: torch.Tensor, k: int = 5) -> Tuple[torch.Tensor, torch.Tensor, Dict[str, float]]:
+        """``search`` with the three steps timed apart (host clock, a device synchronisation after each: a measurement
+        aid, slower than ``search``): milliseconds of this rank's shard search, of the all-gather and of the merge."""
+        def sync():
+            if queries.is_cuda:
+                torch.cuda.synchronize(queries.device)
+        sync()
+        t0 = time.perf_counter()
+        ld, li = self.local_search(queries, k)
+        sync()
+        t1 = time.perf_counter()
+        if self.world == 1:
+            return ld, li, {"local_search_ms": (t1 - t0) * 1e3, "allgather_ms": 0.0, "merge_ms": 0.0}
+        gd, gi = allgather_topk(ld, li, self.group)
+        sync()
+        t2 = time.perf_counter()
+        d, i = self.merge(gd, gi, k)
+        sync()
+        t3 = time.perf_counter()
+        return d, i, {"local_search_ms": (t1 - t0) * 1e3, "allgather_ms": (t2 - t1) * 1e3, "merge_ms": (t3 - t2) * 1e3}
 
 
 def split_batch(total: int, group=None) -> Tuple[int, int]:

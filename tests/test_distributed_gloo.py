@@ -46,7 +46,10 @@ def _worker(rank, world, port, out_dir):
         lo, hi = sharded.split_batch(11)
         emb = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 4)
         allemb = sharded.gather_embeddings(emb, 11)
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), d=d.numpy(), i=i.numpy(), allemb=allemb.numpy())
+        d2, i2, parts = sg.search_timed(torch.from_numpy(q), K)
+        assert torch.equal(i2, i) and set(parts) == {"local_search_ms", "allgather_ms", "merge_ms"}
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), d=d.numpy(), i=i.numpy(), allemb=allemb.numpy(),
+                 digest=np.array(sharded.result_digest(i)))
     finally:
         dist.destroy_process_group()
 
@@ -139,6 +142,13 @@ def test_sharded_search_two_ranks(tmp_path):
     r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
     assert np.array_equal(r0["i"], r1["i"]) and np.array_equal(r0["d"], r1["d"])      # same on every rank
     assert np.array_equal(r0["i"], bi)
+    # what bench.py prints as search.result_digest: the same string from every rank and from one process on the whole gallery
+    one = sharded.ShardedGallery(N, lambda qq, k: tuple(torch.from_numpy(a) for a in (
+        lambda d_, i_: (d_.astype(np.float32), i_.astype(np.int32)))(*matching_ref.l2_topk_bruteforce(qq.numpy(), g, k))))
+    assert one.world == 1
+    d1, i1 = one.search(torch.from_numpy(q), K)
+    assert str(r0["digest"]) == str(r1["digest"]) == sharded.result_digest(i1)
+    assert sharded.result_digest(i1) != sharded.result_digest(i1.flip(0))
     assert r0["i"][0, 0] == 10 and r0["i"][0, 1] == 4000
     assert np.allclose(r0["d"], bd, atol=1e-5)
     assert np.array_equal(r0["allemb"][:, 0], np.arange(11, dtype=np.float32))

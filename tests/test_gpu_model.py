@@ -354,14 +354,16 @@ def test_prepare_facebank_from_image_folders(hip_model, device, state_dict_np, t
 
 
 def test_bench_line_contract():
-    """bench.py prints ONE JSON line with the contract's keys (a short run: small batch, no search / CPU leg)."""
+    """bench.py prints ONE JSON line with the contract's keys (a short run at the benchmark's batch size, a small
+    gallery, no CPU leg)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "64",
-                        "--no-search", "--no-cpu", "--no-latency"], capture_output=True, text=True, timeout=280, cwd=root)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "1024",
+                        "--gallery-rows", "2200000", "--queries", "256", "--search-steps", "1", "--no-cpu", "--no-latency"],
+                       capture_output=True, text=True, timeout=280, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
@@ -380,3 +382,21 @@ def test_bench_line_contract():
     rf = r["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == ("GB/s" if rf["bound"] == "hbm" else "TFLOP/s")
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    # the in-CU floor beside the two rooflines: per kernel the clocks its executed instructions need on the matrix pipe,
+    # the LDS array and the vector ALU (committed profile of this batch size), against this run's launch time
+    assert r["incu_source"] and r["incu_source"].startswith("profiles/")
+    for name, k in r["kernels"].items():
+        u = k["incu"]
+        assert u is not None, name
+        assert u["bound"] in ("mfma", "lds", "valu") and u["floor_us"] == max(u["mfma_us"], u["lds_us"], u["valu_us"])
+        assert 0 < u["frac"] <= 1.0 and abs(u["frac"] - u["floor_us"] / u["launch_us"]) < 2e-3, (name, u)
+        assert u["above_hbm_floor"] == (u["floor_us"] > u["hbm_floor_us"])
+    assert rf["incu"] == r["kernels"][rf["kernel"]]["incu"]
+    # the sharded search: a digest to compare runs at different world sizes with, the three steps apart, and one rank's
+    # share of an 8-GPU run rehearsed on this GPU
+    for s in (r["search_1m"], r["search"]):
+        assert len(s["result_digest"]) == 16 and set(s["shard"]) >= {"rows_per_gpu", "local_search_ms", "allgather_ms", "merge_ms"}
+    s = r["search"]
+    assert s["shard"]["rows_per_gpu"] == 2200000 and s["predicted_8gpu"]["rows_per_gpu"] == 275000
+    assert abs(s["predicted_8gpu_ms"] - (s["predicted_8gpu"]["local_search_ms"] + s["predicted_8gpu"]["merge_ms"]
+                                         + s["predicted_8gpu"]["allgather_assumed_ms"])) < 2e-3
