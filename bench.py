@@ -42,7 +42,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1024, help="crops per GPU per step")
-    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    # f16 only: bf16 activations measure a per-embedding cosine of 0.999 against the fp32 reference, below the 0.9999 bar,
+    # so nothing benchmarked here may use them (the library keeps act_dtype="bf16" as a documented, non-conforming option)
+    ap.add_argument("--dtype", default="f16", choices=["f16"])
     ap.add_argument("--chunk", type=int, default=-1, help="batch slice size inside the library (-1 = tuned default)")
     ap.add_argument("--gallery-rows", type=int, default=100_000_000, help="rows of the WHOLE gallery (sharded over GPUs)")
     ap.add_argument("--queries", type=int, default=10_000)
@@ -364,7 +366,7 @@ def shard_rehearsal(args, dev, shards=8):
     torch.cuda.synchronize()
     local_ms = (time.perf_counter() - t0) / args.search_steps * 1e3
     # `shards` lists per query: this shard's own and copies of it with the indices of the other shards' rows
-    gd = torch.stack([d + 1e-3 * r for r in range(shards)])
+    gd = torch.stack([d + 8.0 * r for r in range(shards)])          # squared distances of unit vectors stay below 4
     gi = torch.stack([i + r * (e - b) for r in range(shards)]).to(torch.int32)
     merge_topk(gd, gi, 5)
     torch.cuda.synchronize()

@@ -16,6 +16,17 @@ void set_error(const char* fmt, ...) {
 
 const char* last_error() { return g_err; }
 
+static std::atomic<long> g_alloc_calls{0};
+hipError_t dev_malloc(void** p, size_t bytes) {
+    g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+    return hipMalloc(p, bytes);
+}
+hipError_t dev_free(void* p) {
+    g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+    return hipFree(p);
+}
+long alloc_calls() { return g_alloc_calls.load(std::memory_order_relaxed); }
+
 // ---- waits that give up: one host-visible word per device ---------------------------------------
 static std::atomic<unsigned*> g_fault_host[64];
 static std::atomic<unsigned*> g_fault_dev[64];
@@ -33,6 +44,7 @@ unsigned* fault_word() {
         unsigned* hp = nullptr;
         void* dp = nullptr;
         // pinned, mapped host memory: a kernel writes it directly, the host reads it without a copy or a synchronisation
+        g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
         if (hipHostMalloc(reinterpret_cast<void**>(&hp), 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && hp) {
             *hp = 0;
             if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess && dp) {
@@ -82,6 +94,7 @@ int fra_device_fault(int device, unsigned* tag_out) {
     if (tag_out) *tag_out = tag;
     return tag ? FRA_ERR_STATE : FRA_OK;
 }
+long fra_dbg_alloc_calls(void) { return fra::alloc_calls(); }
 int fra_dbg_set_spin_limit(int polls) {
     fra::g_spin_limit.store(polls, std::memory_order_relaxed);
     return FRA_OK;

@@ -111,6 +111,13 @@ inline int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_
     return FRA_OK;
 }
 
+// ---- device memory: every allocation and release of the library goes through these two, which count their calls
+// (fra_dbg_alloc_calls): the entry point that promises to allocate nothing is tested by that count standing still
+hipError_t dev_malloc(void** p, size_t bytes);
+hipError_t dev_free(void* p);
+template <typename T> inline hipError_t dev_malloc(T** p, size_t bytes) { return dev_malloc(reinterpret_cast<void**>(p), bytes); }
+long alloc_calls();
+
 // ---- waits that give up ---------------------------------------------------------------------------
 // The kernels that synchronise their waves through words in LDS poll with a bound, so that a protocol bug cannot hang
 // the GPU.  A poll that runs out stores a tag (two letters naming the kernel << 16 | wave) to a host-visible word of the

@@ -595,13 +595,13 @@ static int ensure_scratch(fb_handle* h, size_t bytes) {
     if (h->scratch_bytes >= bytes) return FRA_OK;
     size_t want = bytes > 2 * h->scratch_bytes ? bytes : 2 * h->scratch_bytes;   // geometric growth bounds the retired list
     void* fresh = nullptr;
-    FRA_HIP(hipMalloc(&fresh, want));
+    FRA_HIP(fra::dev_malloc(&fresh, want));
     if (h->scratch) {
         if (h->n_retired < 32) {
             h->retired[h->n_retired++] = h->scratch;
         } else {                       // cannot happen with doubling (2^32 growth); drain and free rather than leak
             (void)hipDeviceSynchronize();
-            (void)hipFree(h->scratch);
+            (void)fra::dev_free(h->scratch);
         }
     }
     h->scratch = fresh;
@@ -634,7 +634,7 @@ static int fill_rows(fb_handle* h, int64_t row0, const float* src, int is_device
     }
     const int64_t step = is_device ? n : (int64_t)(64 << 20) / (D * 4);  // host data goes through a 64 MB bounce
     float* bounce = nullptr;
-    if (!is_device) FRA_HIP(hipMalloc(&bounce, (size_t)step * D * 4));
+    if (!is_device) FRA_HIP(fra::dev_malloc(&bounce, (size_t)step * D * 4));
     int rc = FRA_OK;
     for (int64_t o = 0; o < n && rc == FRA_OK; o += step) {
         const int64_t m = (n - o) < step ? (n - o) : step;
@@ -654,7 +654,7 @@ static int fill_rows(fb_handle* h, int64_t row0, const float* src, int is_device
         hipError_t e = hipStreamSynchronize(s);
         if (e != hipSuccess && rc == FRA_OK) { set_error("fb_fill: pack kernel failed: %s", hipGetErrorString(e)); rc = FRA_ERR_HIP; }
     }
-    if (bounce) (void)hipFree(bounce);
+    if (bounce) (void)fra::dev_free(bounce);
     return rc;
 }
 
@@ -893,11 +893,11 @@ int fb_create(fb_handle** out, int device, const float* gallery, int gallery_is_
     hipError_t e;
     if (store_dtype == FRA_F32) {
         h->Npad = N;
-        e = hipMalloc(&h->rows, (size_t)N * D * 4);
+        e = fra::dev_malloc(&h->rows, (size_t)N * D * 4);
     } else {
         h->Npad = (N + BG - 1) / BG * BG;
-        e = hipMalloc(&h->rows, (size_t)h->Npad * D * 2);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->negh), (size_t)h->Npad * 4);
+        e = fra::dev_malloc(&h->rows, (size_t)h->Npad * D * 2);
+        if (e == hipSuccess) e = fra::dev_malloc(reinterpret_cast<void**>(&h->negh), (size_t)h->Npad * 4);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
         if (e == hipSuccess && h->Npad > N) {
             const long total = (h->Npad - N) * (long)D;
@@ -1031,10 +1031,10 @@ int fb_destroy(fb_handle* h) {
     if (!h) return FRA_OK;
     fra::DeviceGuard guard(h->device);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
-    if (h->rows) (void)hipFree(h->rows);
-    if (h->negh) (void)hipFree(h->negh);
-    if (h->scratch) (void)hipFree(h->scratch);
-    for (int i = 0; i < h->n_retired; ++i) (void)hipFree(h->retired[i]);
+    if (h->rows) (void)fra::dev_free(h->rows);
+    if (h->negh) (void)fra::dev_free(h->negh);
+    if (h->scratch) (void)fra::dev_free(h->scratch);
+    for (int i = 0; i < h->n_retired; ++i) (void)fra::dev_free(h->retired[i]);
     delete h;
     return FRA_OK;
 }

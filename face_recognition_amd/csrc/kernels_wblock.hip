@@ -183,6 +183,7 @@ void wblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
     const int fl_word = OFF_FLAGS + 4 * (lane & 15);
     const int kind = (lane & 15) >> 2, who = lane & 3;
     const bool is_nb = who == wave - 1 || who == wave + 1; // the waves whose rows this wave's windows touch, and who read this wave's
+#ifdef WB_FLAGS
     const int NEVER = -(1 << 30);
     const int d1 = kind == 0 ? 1 : (kind == 2 && is_nb ? 0 : NEVER);            // before expand(s)
     const int d2 = kind == 1 && is_nb ? 1 : (kind == 3 ? 0 : NEVER);            // before the depthwise stage of slice s
@@ -199,6 +200,9 @@ void wblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __re
             __builtin_amdgcn_s_sleep(1);
         }
     };
+#else
+    (void)fl_word; (void)kind; (void)who; (void)is_nb; (void)fault; (void)spin_limit;
+#endif
     auto post = [&](int k, int value) __attribute__((always_inline)) {
         const int a = OFF_FLAGS + 4 * (4 * k + wave);
         LDS_WRITE_U32(a, value);

@@ -458,9 +458,9 @@ static int load_weights(mfn_handle* h, const mfn_tensor_desc* tensors, int n) {
     // a reload overwrites the arena forwards may still be reading (any stream): let the device drain first
     if (h->loaded) FRA_HIP(hipDeviceSynchronize());
     if (h->arena_bytes < off) {
-        if (h->arena) FRA_HIP(hipFree(h->arena));
+        if (h->arena) FRA_HIP(fra::dev_free(h->arena));
         h->arena = nullptr;
-        FRA_HIP(hipMalloc(&h->arena, off));
+        FRA_HIP(fra::dev_malloc(&h->arena, off));
         h->arena_bytes = off;
     }
     FRA_HIP(hipMemcpy(h->arena, host.data(), off, hipMemcpyHostToDevice));
@@ -804,7 +804,7 @@ int mfn_destroy(mfn_handle* h) {
     const int device = h->device;
     if (h->arena) {
         fra::DeviceGuard guard(h->device);
-        (void)hipFree(h->arena);           // waits for the device to drain: every launch of this handle has finished
+        (void)fra::dev_free(h->arena);           // waits for the device to drain: every launch of this handle has finished
     }
     delete h;
     return check_device_fault(device);

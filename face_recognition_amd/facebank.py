@@ -87,7 +87,8 @@ class Gallery:
 
     def fill(self, row0: int, rows: torch.Tensor) -> None:
         """Write rows [row0, row0+len(rows)).  Device rows are packed on the current stream without waiting (later
-        searches on that stream see them); host rows are copied synchronously."""
+        searches on that stream see them); host rows are copied synchronously, after the searches already queued on the
+        current stream have finished (they read the rows being replaced)."""
         rows = rows.detach().to(torch.float32).contiguous()
         with torch.cuda.device(self.device):
             if rows.is_cuda:
@@ -97,6 +98,9 @@ class Gallery:
                 _lib.check(_lib.load().fb_fill_async(self._h, int(row0), rows.data_ptr(), int(rows.shape[0]),
                                                      _lib.current_stream_ptr(self.device)), "fb_fill_async")
             else:
+                # fb_fill copies and packs on a stream of the handle's own: a search queued earlier on the caller's stream
+                # and still running would read rows while they are overwritten, so let that stream drain first
+                torch.cuda.current_stream(self.device).synchronize()
                 _lib.check(_lib.load().fb_fill(self._h, int(row0), rows.data_ptr(), 0, int(rows.shape[0])), "fb_fill")
 
     def reserve(self, max_queries: int) -> None:

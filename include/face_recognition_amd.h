@@ -53,6 +53,10 @@ int fra_version(void);
  * FRA_ERR_STATE and the tag (kernel letters << 16 | wave) if one was set.  Synchronise the stream first to cover the
  * launches still in flight.  No counterpart in the reference. */
 int fra_device_fault(int device, unsigned* tag_out);
+/* Test hook: how many times the library has called a memory allocator (hipMalloc, hipFree, hipHostMalloc) since it was
+ * loaded.  Every such call in the library goes through one counted wrapper, so a count that does not move across a
+ * call proves that the call allocated and freed nothing. */
+long fra_dbg_alloc_calls(void);
 /* Test hook: polls after which such a wait gives up (negative = the built-in bound of about 0.1 s). */
 int fra_dbg_set_spin_limit(int polls);
 
@@ -189,7 +193,9 @@ int fb_create(fb_handle** out, int device, const float* gallery, int gallery_is_
               int store_dtype, int64_t index_base);
 /* Write rows [row0, row0+n) of a gallery created with gallery == NULL (or overwrite rows); lets a
  * large shard be produced piecewise on the device.  Synchronous; runs on a stream of the handle's own, so device
- * rows must be complete when it is called (synchronise their producer stream first) and no other stream is stalled. */
+ * rows must be complete when it is called (synchronise their producer stream first) and no other stream is stalled --
+ * which also means that searches still in flight on other streams read rows while they change: let them finish first
+ * (the Python Gallery.fill synchronises the caller's stream before host rows are written). */
 int fb_fill(fb_handle* h, int64_t row0, const float* rows, int rows_is_device, int64_t n);
 /* fb_fill for device rows, queued on `stream` and not waited for: searches queued on the same stream afterwards see
  * the rows; rows_dev must stay valid until the stream reaches that point. */

@@ -22,6 +22,11 @@ What it does
      the match lines of cam_demo.py:97-105 are evaluated through oracle.matching_ref, which
      is those same expressions.)
   4. cross-checks the CPU restatements under ``oracle/`` against every reference result.
+  5. (``--only calibrated`` runs this step alone) measures, with the REFERENCE model, the mean and variance of the
+     ``linear`` layer's output over 120 verification-style crops, sets the final BatchNorm's running statistics to them
+     -- as a trained network has them: embeddings then spread over the sphere instead of clustering around one direction,
+     which is the regime in which a per-embedding cosine is an honest figure -- and records the reference's embeddings of
+     16 further crops with those weights                        -> embeddings_calibrated.npz
 
 Inputs and weights are regenerated from their seeds at test time, so only seeds and expected
 outputs are stored.
@@ -55,10 +60,43 @@ def import_reference():
     return ref_model, ref_eval
 
 
+def calibrated(ref_model):
+    sd_np = synthetic.make_state_dict(1, 512)
+    net = ref_model.MobileFaceNet(512).eval()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()})
+    taps = []
+    hook = net.linear.register_forward_hook(lambda mod, inp, out: taps.append(out.detach().double()))
+    left, right, _ = synthetic.pair_crops(60, seed=99, noise=0.45)
+    with torch.no_grad():
+        net(torch.from_numpy(np.concatenate([left, right])))
+    hook.remove()
+    z = torch.cat(taps)
+    mean, var = z.mean(0).numpy(), z.var(0, unbiased=False).numpy()
+    sd_cal = synthetic.with_embedding_statistics(sd_np, mean, var)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_cal.items()})
+    l2, r2, _ = synthetic.pair_crops(20, seed=123, noise=0.3)
+    x = torch.from_numpy(np.concatenate([l2[:8], r2[:8]]))
+    with torch.no_grad():
+        y = net(x)
+        y_tta = ref_model.l2_norm(y + net(torch.flip(x, dims=[3])))
+    o = mobilefacenet_ref.forward(sd_cal, x)
+    cosm = (y @ y.t()).numpy()
+    off = cosm[~np.eye(len(cosm), dtype=bool)]
+    print("calibrated: oracle vs reference max|d| %.3g; pairwise cosine of the 16 embeddings: mean %.3f, max %.3f" %
+          ((o - y).abs().max(), off.mean(), off.max()))
+    assert (o - y).abs().max() < 2e-6
+    np.savez_compressed(os.path.join(HERE, "embeddings_calibrated.npz"), weight_seed=1, stat_pairs=60, stat_seed=99,
+                        stat_noise=0.45, bn_running_mean=mean.astype(np.float32), bn_running_var=var.astype(np.float32),
+                        crop_pairs=20, crops_used_per_side=8, crop_seed=123, crop_noise=0.3, emb=y.numpy(), emb_tta=y_tta.numpy())
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref_model, ref_eval = import_reference()
+    if sys.argv[1:3] == ["--only", "calibrated"]:
+        calibrated(ref_model)
+        return
 
     # ---- 1. embeddings ------------------------------------------------------------------
     W_SEED, X_SEED, B = 1, 0, 4
@@ -143,6 +181,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "facebank_match.npz"), facebank=fb.numpy(), names=names,
                         queries=q.numpy(), pairwise_d2=d2.numpy(), **res)
     print("wrote fixtures to", HERE)
+    calibrated(ref_model)
 
 
 if __name__ == "__main__":

@@ -248,6 +248,24 @@ def test_fill_is_ordered_on_the_current_stream(device):
     assert i.cpu().flatten().tolist() == [5, 4321] and float(d.abs().max()) < 1e-3
 
 
+def test_host_fill_waits_for_searches_in_flight(device):
+    """Host rows are written on a stream of the handle's own: a search queued before the fill on the caller's stream
+    must have read the OLD rows (Gallery.fill lets that stream drain first)."""
+    old = torch.from_numpy(synthetic.unit_rows(200000, 512, seed=3)).to(device)
+    new = synthetic.unit_rows(200000, 512, seed=33)
+    gal = Gallery(old, store="f16", device=device)
+    q = old[::1000].contiguous()                         # 200 queries, each the copy of a row of the old gallery
+    big = torch.randn((4096, 4096), device=device)
+    for _ in range(4):
+        big = big @ big * 1e-3                           # the search below is queued behind this
+    d, i = gal.search(q, 1)
+    gal.fill(0, torch.from_numpy(new))                   # replaces every row
+    torch.cuda.synchronize()
+    assert torch.equal(i.flatten().cpu(), torch.arange(0, 200000, 1000, dtype=torch.int32)) and float(d.abs().max()) < 1e-3
+    d2, i2 = gal.search(torch.from_numpy(new[[7, 150001]]).to(device), 1)
+    assert i2.flatten().cpu().tolist() == [7, 150001]
+
+
 def test_facebank_errors(device):
     with pytest.raises(RuntimeError):
         Gallery(torch.zeros((4, 100)), store="f16", device=device)      # packed search needs D == 512

@@ -25,6 +25,22 @@ def test_oracle_embeddings_match_reference_golden(golden_dir, state_dict_np):
     assert y128.shape == (2, 128) and np.abs(y128 - z["emb128_seed7_b2"]).max() < 5e-6
 
 
+def test_oracle_matches_reference_on_calibrated_weights(golden_dir, state_dict_np):
+    """Weights whose final BatchNorm carries the statistics of the `linear` layer's output (measured with the reference
+    model, stored in the fixture): embeddings spread over the sphere; the oracle reproduces the reference's outputs."""
+    import os
+    z = np.load(os.path.join(golden_dir, "embeddings_calibrated.npz"))
+    sd = synthetic.with_embedding_statistics(state_dict_np, z["bn_running_mean"], z["bn_running_var"])
+    left, right, _ = synthetic.pair_crops(int(z["crop_pairs"]), seed=int(z["crop_seed"]), noise=float(z["crop_noise"]))
+    n = int(z["crops_used_per_side"])
+    x = torch.from_numpy(np.concatenate([left[:n], right[:n]]))
+    y = mobilefacenet_ref.forward(sd, x).numpy()
+    assert np.abs(y - z["emb"]).max() < 2e-6
+    assert np.abs(mobilefacenet_ref.embed_tta(sd, x).numpy() - z["emb_tta"]).max() < 2e-6
+    c = z["emb"] @ z["emb"].T
+    assert abs(c[~np.eye(len(c), dtype=bool)].mean()) < 0.2          # spread, not clustered
+
+
 def test_oracle_rows_are_unit_norm_and_flip_matters(state_dict_np):
     x = torch.from_numpy(synthetic.make_crops(2, 5))
     y = mobilefacenet_ref.forward(state_dict_np, x)

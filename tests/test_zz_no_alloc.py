@@ -39,9 +39,17 @@ def test_noalloc_search_equals_allocating_search(device, store, N):
             qn, _ = synthetic.planted_queries(g.cpu().numpy(), Q, seed=seed)
             q = torch.from_numpy(qn).to(device)
             want_d, want_i = _search(lib, "fb_search_l2_topk", h, q, k, device)
-            before = torch.cuda.memory_allocated(device)
-            got_d, got_i = _search(lib, "fb_search_l2_topk_noalloc", h, q, k, device)
-            assert torch.cuda.memory_allocated(device) >= before     # torch's view only; the C side has no allocator call
+            dist = torch.full((Q, k), -7.0, dtype=torch.float32, device=device)
+            idx = torch.full((Q, k), -7, dtype=torch.int32, device=device)
+            torch.cuda.synchronize(device)
+            # the library counts its own allocator calls (every hipMalloc / hipFree / hipHostMalloc it makes goes through
+            # one wrapper): the count must stand still across the call
+            before = lib.fra_dbg_alloc_calls()
+            _lib.check(lib.fb_search_l2_topk_noalloc(h, q.data_ptr(), Q, k, dist.data_ptr(), idx.data_ptr(),
+                                                     _lib.current_stream_ptr(device)), "fb_search_l2_topk_noalloc")
+            torch.cuda.synchronize(device)
+            assert lib.fra_dbg_alloc_calls() == before
+            got_d, got_i = dist.cpu(), idx.cpu()
             assert torch.equal(got_i, want_i), (store, Q, k)
             assert torch.equal(got_d, want_d), (store, Q, k)
             assert (got_i >= 0).all()
@@ -52,17 +60,21 @@ def test_noalloc_search_equals_allocating_search(device, store, N):
 def test_noalloc_search_refuses_what_does_not_fit(device):
     lib = _lib.load()
     g = torch.from_numpy(synthetic.unit_rows(3000, 512, seed=3)).to(device)
-    q = torch.from_numpy(synthetic.unit_rows(1024, 512, seed=9)).to(device)
-    for store in ("f32", "f16"):          # fp32: 1024 x 3000 distances = 12 MB; f16: 1024 queries x 256 lists x 8
+    # searches that exceed the 8 MiB array whatever the GPU's compute-unit count (which sets the number of partial lists):
+    # fp32: 1024 x 3000 distances = 12 MB; f16: the 16-bit copies of 9000 queries alone are 9.2 MB
+    for store, Q in (("f32", 1024), ("f16", 9000)):
+        q = torch.from_numpy(synthetic.unit_rows(Q, 512, seed=9)).to(device)
         h = _create(lib, g, store, device)
         try:
-            dist = torch.empty((1024, 8), dtype=torch.float32, device=device)
-            idx = torch.empty((1024, 8), dtype=torch.int32, device=device)
-            rc = lib.fb_search_l2_topk_noalloc(h, q.data_ptr(), 1024, 8, dist.data_ptr(), idx.data_ptr(),
+            dist = torch.empty((Q, 8), dtype=torch.float32, device=device)
+            idx = torch.empty((Q, 8), dtype=torch.int32, device=device)
+            before = lib.fra_dbg_alloc_calls()
+            rc = lib.fb_search_l2_topk_noalloc(h, q.data_ptr(), Q, 8, dist.data_ptr(), idx.data_ptr(),
                                                _lib.current_stream_ptr(device))
             assert rc == 1 and b"static array holds" in lib.fra_last_error()
+            assert lib.fra_dbg_alloc_calls() == before
             # the allocating entry point takes the same search
-            _lib.check(lib.fb_search_l2_topk(h, q.data_ptr(), 1024, 8, dist.data_ptr(), idx.data_ptr(),
+            _lib.check(lib.fb_search_l2_topk(h, q.data_ptr(), Q, 8, dist.data_ptr(), idx.data_ptr(),
                                              _lib.current_stream_ptr(device)), "fb_search_l2_topk")
             torch.cuda.synchronize(device)
         finally:
