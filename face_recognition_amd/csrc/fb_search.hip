@@ -10,8 +10,13 @@
 //
 // Ordering everywhere: ascending distance, equal distances -> lower index first.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
+
+#ifndef SEARCH_WIDE_DEFAULT
+#define SEARCH_WIDE_DEFAULT 0
+#endif
 
 struct fb_handle {
     int device = 0;
@@ -134,25 +139,59 @@ template <int KS> struct TopList {
 static const int SEARCH_KSTEPS = SEARCH_D / 32;                  // k-steps of one chain
 static const int SEARCH_CHAINS = BG / 16;                        // chains of one tile (3)
 static const int SEARCH_STEPS = SEARCH_CHAINS * SEARCH_KSTEPS;   // steps of one tile
-static const int SEARCH_PIECES = BG / 8;                         // 1 KB rows each wave stages per tile
 static const int SEARCH_TILE_BYTES = BG * SEARCH_D * 2;          // 49152
 static const int SEARCH_BUF_BYTES = SEARCH_TILE_BYTES + 256;     // + bias terms (a 64-lane load fills 256 B)
 
+// The block's 256 queries are dealt to its waves QTW tiles of 16 each: QTW = 2 is eight waves, two to a SIMD; QTW = 4 is
+// FOUR waves, one to a SIMD, each with the whole 512-entry register file: every gallery fragment read from LDS then
+// feeds four matrix instructions instead of two (half the LDS reads per multiply-add), the 256 registers of query
+// fragments sit in the accumulation half of the file (the MFMAs are inline assembly with an "a" operand for them) and
+// one in-order stream of four MFMAs per step keeps the matrix pipe busy without a partner wave.
+template <int QTW> struct SearchGeom {
+    static constexpr int NWV = BQ / (16 * QTW);                  // waves of a block
+    static constexpr int PIECES = BG / NWV;                      // 1 KB rows each wave stages per tile
+    static constexpr int PIECE_EVERY = SEARCH_STEPS / PIECES;    // a piece goes out every so many steps ...
+    static constexpr int PIECE_AT = PIECE_EVERY / 2 - 1;         // ... at this step of each group
+    static constexpr int NSRC = 16 / NWV;                        // distinct swizzles (row & 15) among a wave's rows
+    static_assert(BQ % (16 * QTW) == 0 && BG % NWV == 0 && SEARCH_STEPS % PIECES == 0 && 16 % NWV == 0, "geometry");
+};
+
+// one MFMA of the search: gallery fragment a (rows), query fragment b (columns)
+template <int QTW> struct SearchMma {
+    // eight waves: the compiler's own instruction
+    template <typename V8> static __device__ __forceinline__ void first(f32x4& d, V8 a, V8 b, f32x4 c) { d = mfma16(a, b, c); }
+    template <typename V8> static __device__ __forceinline__ void next(f32x4& d, V8 a, V8 b) { d = mfma16(a, b, d); }
+};
+template <> struct SearchMma<4> {
+    // four wide waves: the query fragment comes from an accumulation register
+    static __device__ __forceinline__ void first(f32x4& d, vec8<f16>::type a, vec8<f16>::type b, f32x4 c) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+    }
+    static __device__ __forceinline__ void next(f32x4& d, vec8<f16>::type a, vec8<f16>::type b) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+    }
+    static __device__ __forceinline__ void first(f32x4& d, vec8<bf16>::type a, vec8<bf16>::type b, f32x4 c) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+    }
+    static __device__ __forceinline__ void next(f32x4& d, vec8<bf16>::type a, vec8<bf16>::type b) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+    }
+};
+
 // NB = A-fragment register slots (a divisor of SEARCH_STEPS so the ring carries across tiles);
 // reads run PD = NB - 1 steps ahead
-template <typename T, int KS, int NB> struct SearchCtx {
+template <typename T, int KS, int NB, int QTW> struct SearchCtx {
     typedef typename vec8<T>::type V8;
-    V8 qf[SEARCH_KSTEPS][2];       // query fragments
+    V8 qf[SEARCH_KSTEPS][QTW];     // query fragments
     V8 af[NB];                     // ring of gallery fragments
-    f32x4 acc[SEARCH_CHAINS][2];   // [chain][query tile]
+    f32x4 acc[SEARCH_CHAINS][QTW]; // [chain][query tile]
     f32x4 bias;                    // -|g|^2/2 of the chain's 4 rows of this lane
-    TopList<KS> top[2];            // per query tile
+    TopList<KS> top[QTW];          // per query tile
     int bl[4], bn[4];              // lane part of the fragment address for k-step & 3: this tile, next tile
     int nha, nhn;                  // LDS address of this lane's bias terms of chain 0: this tile, next tile
     int kg;
     // staging of the tile two ahead
-    const T* gsrc;                 // this lane's source of piece 0 (even pieces)
-    const T* gsrc_odd;             // same for odd pieces (the swizzle differs by one bit)
+    const T* gsrc[SearchGeom<QTW>::NSRC];   // this lane's source of piece p: gsrc[p % NSRC] (the swizzle follows row & 15)
     const float* nsrc;             // bias source (wave 0)
     char* ldst;                    // LDS destination of piece 0
     int wave;
@@ -160,14 +199,18 @@ template <typename T, int KS, int NB> struct SearchCtx {
 };
 
 // fold chain `rt` of the tile whose first row is row0 into the lists
-template <typename Ctx, int KS>
+template <typename Ctx, int KS, int QTW>
 __device__ __forceinline__ void fold_chain(Ctx& c, int row0, int rt) {
-    const float m0 = fmaxf(fmaxf(c.acc[rt][0][0], c.acc[rt][0][1]), fmaxf(c.acc[rt][0][2], c.acc[rt][0][3]));
-    const float m1 = fmaxf(fmaxf(c.acc[rt][1][0], c.acc[rt][1][1]), fmaxf(c.acc[rt][1][2], c.acc[rt][1][3]));
-    if (__any(m0 > c.top[0].s[KS - 1] || m1 > c.top[1].s[KS - 1])) {
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < QTW; ++u) {
+        const float m = fmaxf(fmaxf(c.acc[rt][u][0], c.acc[rt][u][1]), fmaxf(c.acc[rt][u][2], c.acc[rt][u][3]));
+        any = any || m > c.top[u].s[KS - 1];
+    }
+    if (__any(any)) {
         const int rbase = row0 + 16 * rt + 4 * c.kg;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < QTW; ++u)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float v = c.acc[rt][u][i];
@@ -176,14 +219,17 @@ __device__ __forceinline__ void fold_chain(Ctx& c, int row0, int rt) {
     }
 }
 
-template <typename T, int KS, int NB, int S> struct SearchSteps {
+template <typename T, int KS, int NB, int QTW, int S> struct SearchSteps {
     typedef typename vec8<T>::type V8;
-    typedef SearchCtx<T, KS, NB> Ctx;
+    typedef SearchCtx<T, KS, NB, QTW> Ctx;
+    typedef SearchGeom<QTW> GEO;
+    typedef SearchMma<QTW> MMA;
     static constexpr int PD = NB - 1;
     static constexpr int BARRIER_STEP = SEARCH_STEPS - PD - 1;   // the step after which the next tile is first read
-    static constexpr int PIECES_BEFORE_BARRIER = (BARRIER_STEP - 3) / 8 + 1;   // pieces go out at steps 8 p + 3
+    // pieces go out at steps PIECE_EVERY p + PIECE_AT: those issued up to the barrier step
+    static constexpr int PIECES_BEFORE_BARRIER = (BARRIER_STEP - GEO::PIECE_AT) / GEO::PIECE_EVERY + 1;
     static_assert(SEARCH_STEPS % NB == 0, "ring slots must line up across tiles");
-    static_assert(8 * (SEARCH_PIECES - 1) + 3 < SEARCH_STEPS, "every piece needs a step");
+    static_assert(GEO::PIECE_EVERY * (GEO::PIECES - 1) + GEO::PIECE_AT < SEARCH_STEPS && GEO::PIECE_AT >= 0, "every piece needs a step");
     // reads issued after the fragment of step ss and before its wait: the PD fragments that follow
     // (into the next tile if need be) plus the bias reads that precede a chain's first fragment
     static constexpr int ahead(int ss) {
@@ -206,16 +252,16 @@ template <typename T, int KS, int NB, int S> struct SearchSteps {
     static __device__ __forceinline__ void prologue(Ctx& c) {
         if constexpr (S < PD) {
             read_step<S>(c);
-            SearchSteps<T, KS, NB, S + 1>::prologue(c);
+            SearchSteps<T, KS, NB, QTW, S + 1>::prologue(c);
         }
     }
-    // one piece (a 1 KB row) of the tile two ahead; wave w stages rows w, w + 8, ...
+    // one piece (a 1 KB row) of the tile two ahead; wave w stages rows w, w + NWV, ...
     template <int PIECE> static __device__ __forceinline__ void stage_piece(Ctx& c) {
         if (c.do_stage) {
-            constexpr int row8 = PIECE * 8;
-            __builtin_amdgcn_global_load_lds((GPTR)(((PIECE & 1) ? c.gsrc_odd : c.gsrc) + (size_t)row8 * SEARCH_D),
+            constexpr int row8 = PIECE * GEO::NWV;
+            __builtin_amdgcn_global_load_lds((GPTR)(c.gsrc[PIECE % GEO::NSRC] + (size_t)row8 * SEARCH_D),
                                              (LPTR)(c.ldst + row8 * (SEARCH_D * 2)), 16, 0, 0);
-            if (PIECE == SEARCH_PIECES - 1 && c.wave == 0)   // wave 0: ldst is the buffer base
+            if (PIECE == GEO::PIECES - 1 && c.wave == 0)   // wave 0: ldst is the buffer base
                 __builtin_amdgcn_global_load_lds((GPTR)c.nsrc, (LPTR)(c.ldst + SEARCH_TILE_BYTES), 4, 0, 0);
         }
     }
@@ -227,17 +273,17 @@ template <typename T, int KS, int NB, int S> struct SearchSteps {
                 // wait for this step's fragment and the chain's bias; both are named so that their
                 // consumers cannot be moved above the wait
                 asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c.af[slot]), "+v"(c.bias) : "n"(ahead(S)));
-                c.acc[rt][0] = mfma16(c.af[slot], c.qf[0][0], c.bias);
-                c.acc[rt][1] = mfma16(c.af[slot], c.qf[0][1], c.bias);
+#pragma unroll
+                for (int u = 0; u < QTW; ++u) MMA::first(c.acc[rt][u], c.af[slot], c.qf[0][u], c.bias);
             } else {
                 asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(c.af[slot]) : "n"(ahead(S)));
-                c.acc[rt][0] = mfma16(c.af[slot], c.qf[ks][0], c.acc[rt][0]);
-                c.acc[rt][1] = mfma16(c.af[slot], c.qf[ks][1], c.acc[rt][1]);
+#pragma unroll
+                for (int u = 0; u < QTW; ++u) MMA::next(c.acc[rt][u], c.af[slot], c.qf[ks][u]);
             }
-            if constexpr ((S & 7) == 3 && S / 8 < SEARCH_PIECES) stage_piece<S / 8>(c);
+            if constexpr (S % GEO::PIECE_EVERY == GEO::PIECE_AT && S / GEO::PIECE_EVERY < GEO::PIECES) stage_piece<S / GEO::PIECE_EVERY>(c);
             if constexpr (ks == 2) {   // the previous chain finished two steps ago: fold it in under this chain
-                if constexpr (rt == 0) { if (have_prev) fold_chain<Ctx, KS>(c, row0 - BG, SEARCH_CHAINS - 1); }
-                else fold_chain<Ctx, KS>(c, row0, rt - 1);
+                if constexpr (rt == 0) { if (have_prev) fold_chain<Ctx, KS, QTW>(c, row0 - BG, SEARCH_CHAINS - 1); }
+                else fold_chain<Ctx, KS, QTW>(c, row0, rt - 1);
             }
             if constexpr (S == BARRIER_STEP) {
                 // tile barrier, just before the first read of the next tile: this wave's pieces of the
@@ -247,22 +293,23 @@ template <typename T, int KS, int NB, int S> struct SearchSteps {
                 __builtin_amdgcn_s_barrier();
             }
             __builtin_amdgcn_sched_barrier(0);
-            SearchSteps<T, KS, NB, S + 1>::run(c, row0, have_prev);
+            SearchSteps<T, KS, NB, QTW, S + 1>::run(c, row0, have_prev);
         }
     }
 };
 
-template <typename T, int KS>
-__global__ __launch_bounds__(512) void search_kernel(const T* __restrict__ G, const float* __restrict__ negh,
-                                                     const T* __restrict__ Qh, const float* __restrict__ qn,
-                                                     float* __restrict__ pdist, int* __restrict__ pidx,
-                                                     const float* __restrict__ qfloor, int tile0,
-                                                     int tiles_total, int tiles_per_split, int QT, int S, int Qpad,
-                                                     int index_base) {
+template <typename T, int KS, int QTW>
+__device__ __forceinline__ void search_body(const T* __restrict__ G, const float* __restrict__ negh,
+                                            const T* __restrict__ Qh, const float* __restrict__ qn,
+                                            float* __restrict__ pdist, int* __restrict__ pidx,
+                                            const float* __restrict__ qfloor, int tile0,
+                                            int tiles_total, int tiles_per_split, int QT, int S, int Qpad,
+                                            int index_base) {
     typedef typename vec8<T>::type V8;
+    typedef SearchGeom<QTW> GEO;
     constexpr int D = SEARCH_D, CH = D / 8;
-    constexpr int NB = KS > 5 ? 6 : 8;   // the longer top-k lists leave room for fewer fragment slots
-    typedef SearchCtx<T, KS, NB> Ctx;
+    constexpr int NB = (KS > 5 && QTW == 2) ? 6 : 8;   // eight waves: the longer top-k lists leave room for fewer fragment slots
+    typedef SearchCtx<T, KS, NB, QTW> Ctx;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -285,16 +332,16 @@ __global__ __launch_bounds__(512) void search_kernel(const T* __restrict__ G, co
     c.kg = kg;
     c.wave = wave;
     // query fragments (MFMA B operand): lane (col, kg) holds Q[q][32 s + 8 kg .. +8] of query col of tile u
-    const int qrow0 = qt * BQ + wave * 32 + col;
+    const int qrow0 = qt * BQ + wave * (16 * QTW) + col;
 #pragma unroll
     for (int s = 0; s < SEARCH_KSTEPS; ++s)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < QTW; ++u)
             c.qf[s][u] = *reinterpret_cast<const V8*>(Qh + (size_t)(qrow0 + 16 * u) * D + s * 32 + kg * 8);
     // qfloor: per query a score that its k-th best row is known to beat (from a pass over other rows); the lists
     // then skip everything below it from their first row on instead of filling up with whatever comes first
-    c.top[0].init(qfloor ? qfloor[qrow0] : -INFINITY);
-    c.top[1].init(qfloor ? qfloor[qrow0 + 16] : -INFINITY);
+#pragma unroll
+    for (int u = 0; u < QTW; ++u) c.top[u].init(qfloor ? qfloor[qrow0 + 16 * u] : -INFINITY);
 
     // A fragment of step (rt, ks): row 16 rt + col, chunk 4 ks + kg  ->  lane part lo[ks & 3] plus the
     // compile-time part 256 (ks >> 2) + 16384 rt
@@ -303,16 +350,18 @@ __global__ __launch_bounds__(512) void search_kernel(const T* __restrict__ G, co
 #pragma unroll
     for (int j = 0; j < 4; ++j) lo[j] = col * (CH * 16) + (((4 * j + kg) ^ col) << 4);
 
-    // staging: piece p of a tile is row 8 p + wave, and lane l fetches the chunk that belongs at
-    // position l of that row: l ^ (row & 15) = l ^ wave for even p, (l ^ wave) ^ 8 for odd p
-    const int ch_even = lane ^ wave, ch_odd = ch_even ^ 8;
+    // staging: piece p of a tile is row NWV p + wave, and lane l fetches the chunk that belongs at
+    // position l of that row: l ^ (row & 15), which takes NSRC values over a wave's pieces
+    int chv[GEO::NSRC];
+#pragma unroll
+    for (int j = 0; j < GEO::NSRC; ++j) chv[j] = lane ^ ((GEO::NWV * j + wave) & 15);
     auto stage_all = [&](int tile, int bufsel) {
         char* base = smem + bufsel * SEARCH_BUF_BYTES;
         const T* gt = G + (size_t)tile * BG * D;
 #pragma unroll
-        for (int i = 0; i < SEARCH_PIECES; ++i) {
-            const int row = i * 8 + wave;
-            __builtin_amdgcn_global_load_lds((GPTR)(gt + (size_t)row * D + ((i & 1) ? ch_odd : ch_even) * 8),
+        for (int i = 0; i < GEO::PIECES; ++i) {
+            const int row = i * GEO::NWV + wave;
+            __builtin_amdgcn_global_load_lds((GPTR)(gt + (size_t)row * D + chv[i % GEO::NSRC] * 8),
                                              (LPTR)(base + row * (CH * 16)), 16, 0, 0);
         }
         if (wave == 0)   // lanes past the tile's rows re-read row 0 into the padding of the bias area
@@ -332,7 +381,7 @@ __global__ __launch_bounds__(512) void search_kernel(const T* __restrict__ G, co
         for (int j = 0; j < 4; ++j) c.bl[j] = lo[j] + lds0;
         c.nha = lds0 + SEARCH_TILE_BYTES + 16 * kg;
         __builtin_amdgcn_sched_barrier(0);
-        SearchSteps<T, KS, NB, 0>::prologue(c);
+        SearchSteps<T, KS, NB, QTW, 0>::prologue(c);
         for (int t = t_begin; t < t_end; ++t) {
             const int nxt = cur == 2 ? 0 : cur + 1, nn = nxt == 2 ? 0 : nxt + 1;
             // the reads that run ahead into the next tile are issued for the last tile as well (from
@@ -344,10 +393,10 @@ __global__ __launch_bounds__(512) void search_kernel(const T* __restrict__ G, co
             c.do_stage = t + 2 < t_end;
             c.ldst = smem + nn * SEARCH_BUF_BYTES + wave * (CH * 16);
             c.nsrc = negh + (size_t)(t + 2) * BG + (lane < BG ? lane : 0);
-            c.gsrc = G + (size_t)(t + 2) * BG * D + (size_t)wave * D + ch_even * 8;
-            c.gsrc_odd = G + (size_t)(t + 2) * BG * D + (size_t)wave * D + ch_odd * 8;
+#pragma unroll
+            for (int j = 0; j < GEO::NSRC; ++j) c.gsrc[j] = G + (size_t)(t + 2) * BG * D + (size_t)wave * D + chv[j] * 8;
             __builtin_amdgcn_sched_barrier(0);
-            SearchSteps<T, KS, NB, 0>::run(c, t * BG, t > t_begin);
+            SearchSteps<T, KS, NB, QTW, 0>::run(c, t * BG, t > t_begin);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) c.bl[j] = c.bn[j];
@@ -358,12 +407,12 @@ __global__ __launch_bounds__(512) void search_kernel(const T* __restrict__ G, co
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c.bias));
 #pragma unroll
         for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(c.af[i]));
-        fold_chain<Ctx, KS>(c, (t_end - 1) * BG, SEARCH_CHAINS - 1);
+        fold_chain<Ctx, KS, QTW>(c, (t_end - 1) * BG, SEARCH_CHAINS - 1);
     }
 
     // partial lists: [P = 4 S][Qpad][KS], list p = 4 split + kg
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < QTW; ++u) {
         const int qrow = qrow0 + 16 * u;
         const float q2 = qn[qrow];
         const size_t o = ((size_t)(4 * split + kg) * Qpad + qrow) * KS;
@@ -374,6 +423,27 @@ __global__ __launch_bounds__(512) void search_kernel(const T* __restrict__ G, co
             pidx[o + j] = ok ? c.top[u].id[j] + index_base : -1;
         }
     }
+}
+
+template <typename T, int KS>
+__global__ __launch_bounds__(512) void search_kernel(const T* __restrict__ G, const float* __restrict__ negh,
+                                                     const T* __restrict__ Qh, const float* __restrict__ qn,
+                                                     float* __restrict__ pdist, int* __restrict__ pidx,
+                                                     const float* __restrict__ qfloor, int tile0,
+                                                     int tiles_total, int tiles_per_split, int QT, int S, int Qpad,
+                                                     int index_base) {
+    search_body<T, KS, 2>(G, negh, Qh, qn, pdist, pidx, qfloor, tile0, tiles_total, tiles_per_split, QT, S, Qpad, index_base);
+}
+// four wide waves, one per SIMD (SearchGeom above)
+template <typename T, int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void search_kernel_wide(const T* __restrict__ G, const float* __restrict__ negh,
+                        const T* __restrict__ Qh, const float* __restrict__ qn,
+                        float* __restrict__ pdist, int* __restrict__ pidx,
+                        const float* __restrict__ qfloor, int tile0,
+                        int tiles_total, int tiles_per_split, int QT, int S, int Qpad,
+                        int index_base) {
+    search_body<T, KS, 4>(G, negh, Qh, qn, pdist, pidx, qfloor, tile0, tiles_total, tiles_per_split, QT, S, Qpad, index_base);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -689,7 +759,16 @@ template <typename T, int KSV>
 static int launch_search(const dim3 grid, size_t lds, hipStream_t s, const T* G, const float* negh, const T* qh,
                          const float* qn, float* pd, int* pi, const float* qfloor, int tile0, int tiles, int tps, int QT, int S,
                          int Qpad, int index_base) {
-    static std::atomic<uint64_t> lds_set;      // per instantiation: devices whose LDS limit is raised
+    static std::atomic<uint64_t> lds_set, lds_set_wide;      // per instantiation: devices whose LDS limit is raised
+    // FRA_SEARCH_WIDE=0|1 picks the eight-wave or the four-wide-wave kernel (same results; measurements)
+    static const bool wide = [] { const char* e = getenv("FRA_SEARCH_WIDE"); return e ? atoi(e) != 0 : SEARCH_WIDE_DEFAULT != 0; }();
+    if (wide) {
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&search_kernel_wide<T, KSV>), (int)lds, lds_set_wide)) return rc;
+        hipLaunchKernelGGL((search_kernel_wide<T, KSV>), grid, dim3(256), lds, s, G, negh, qh, qn, pd, pi, qfloor, tile0, tiles, tps,
+                           QT, S, Qpad, index_base);
+        FRA_HIP(hipGetLastError());
+        return FRA_OK;
+    }
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&search_kernel<T, KSV>), (int)lds, lds_set)) return rc;
     hipLaunchKernelGGL((search_kernel<T, KSV>), grid, dim3(512), lds, s, G, negh, qh, qn, pd, pi, qfloor, tile0, tiles, tps, QT,
                        S, Qpad, index_base);
