@@ -187,7 +187,10 @@ int launch_pblock(int dt, const BlockParams& p, const void* x, void* out, int B,
 // ---- residual blocks with the activation kept in registers between blocks (kernels_rblock.hip) ----------------
 // Everything one 64-channel slice of one block needs travels as ONE package, stored in global memory exactly as it
 // sits in LDS (padding included), so a package is copied by 1 KB LDS-DMA pieces:
-//   W1 image | W3 image | b1 | s1 | b2 | s2 | 3x3 weight image | b3      (rounded up to whole pieces)
+//   expand group: W1 image | b1 | s1 (rounded up to whole pieces)
+//   depthwise / project group: W3 image | b2 | s2 | 3x3 weight image | b3      (rounded up to whole pieces)
+// The expand stage reads the first group only, the depthwise + project stage and the block epilogue the second only, so
+// a kernel may keep the two in separate LDS buffers and load them at different times.
 // W1 image: 4 channel tiles x 32 rows of C/2 elements + one 16-byte unit of padding; row 16 p + m of tile t holds,
 //   for expanded channel 64 c + 16 t + m, the units [ks][g >> 1] of the k-groups g with g & 1 == p, where element j
 //   of k-step ks, k-group g is INPUT channel rb_in_channel(ks, g, j) -- the order in which a lane of the project
@@ -206,11 +209,14 @@ constexpr int dw_wrow(int ch) { return 2 * dw_wplane(ch); }
 constexpr int dw_wimage_bytes(int ch) { return 3 * dw_wrow(ch); }
 template <int C> struct RbPkg {
     static constexpr int PW1 = C + 16, W1_BYTES = 128 * PW1;
-    static constexpr int PW3 = 80, W3_BYTES = 2 * C * PW3, OFF_W3 = W1_BYTES;
-    static constexpr int OFF_B1 = OFF_W3 + W3_BYTES, OFF_S1 = OFF_B1 + 256, OFF_B2 = OFF_S1 + 256, OFF_S2 = OFF_B2 + 256;
+    static constexpr int OFF_B1 = W1_BYTES, OFF_S1 = OFF_B1 + 256;
+    static constexpr int EG_BYTES = (OFF_S1 + 256 + 1023) / 1024 * 1024, EG_PIECES = EG_BYTES / 1024;   // expand group
+    static constexpr int PW3 = 80, W3_BYTES = 2 * C * PW3, OFF_W3 = EG_BYTES;
+    static constexpr int OFF_B2 = OFF_W3 + W3_BYTES, OFF_S2 = OFF_B2 + 256;
     static constexpr int OFF_W2 = OFF_S2 + 256, OFF_B3 = OFF_W2 + dw_wimage_bytes(64);
     static constexpr int RAW = OFF_B3 + C * 4;
     static constexpr int BYTES = (RAW + 1023) / 1024 * 1024, PIECES = BYTES / 1024;
+    static constexpr int DG_BYTES = BYTES - EG_BYTES, DG_PIECES = DG_BYTES / 1024;                      // depthwise / project group
 };
 inline int rb_in_channel(int ks, int g, int j) { return 16 * (2 * ks + (j >> 2)) + 4 * g + (j & 3); }
 inline int rb_pos(int e_local) { return 16 * ((e_local >> 2) & 3) + 4 * (e_local >> 4) + (e_local & 3); }

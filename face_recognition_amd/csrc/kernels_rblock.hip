@@ -132,6 +132,41 @@ extern "C" int fra_dbg_read(void* dst, size_t bytes) {
 #ifndef RB_FLAGS
 #define RB_FLAGS 1         // whole-image workgroups synchronise wave to wave through flags in LDS instead of barriers
 #endif
+#ifndef RB_OPPOSED
+#define RB_OPPOSED 0       // 1: whole-image workgroups synchronise once per ROUND (depthwise stage of slice r + expand stage of slice
+                           // r + 1, the two waves of a SIMD in opposite order).  Same bits; measured at batch 1024, six blocks of
+                           // conv_4, one box: 322-324 us against 312-315 us for the slice loop (every wave depthwise-first: 316)
+#endif
+#ifndef RB_EXPAND_FIRST_WAVES
+#define RB_EXPAND_FIRST_WAVES 0x0F   // bit w: wave w runs a round's expand stage before its depthwise stage (the first wave of each SIMD)
+#endif
+// -DRB_PRIO_POLICY=n (experiments): issue priority of the two waves of a SIMD by stage.  old = dispatched first (waves 0-3)
+//   1: young waves 1 throughout, old waves 1 in the expand stage and 0 in the depthwise stage;  2: the reverse for the old waves;
+//   3: every wave 1 in its depthwise stage, 0 in its expand stage;  4: old waves as 3, young waves the reverse
+//   6-8: as 3 with the young (6, 7) or the old (8) waves one level higher.   Batch 1024, six blocks of conv_4, one box, us per
+//   launch: 0: 307.4  1: 303.3  2: 301.8  3: 300.7-302.0  4: 309.0  6: 304.6  7: 301.0  8: 302.4  (young waves 1 always: 308.5)
+#ifndef RB_PRIO_POLICY
+#define RB_PRIO_POLICY 3
+#endif
+#if RB_PRIO_POLICY == 0
+#define RB_PRIO_STAGE(stage)
+#else
+#define RB_PRIO_STAGE(stage)                                                                              \
+    do {                                                                                                  \
+        const bool old_ = wave < NW / 2;                                                                  \
+        int lvl_;                                                                                         \
+        if (RB_PRIO_POLICY == 1) lvl_ = !old_ || (stage) == 0;                                            \
+        else if (RB_PRIO_POLICY == 2) lvl_ = !old_ || (stage) == 1;                                       \
+        else if (RB_PRIO_POLICY == 3) lvl_ = (stage) == 1;                                                \
+        else if (RB_PRIO_POLICY == 4) lvl_ = old_ ? (stage) == 1 : (stage) == 0;                          \
+        else if (RB_PRIO_POLICY == 6) lvl_ = ((stage) == 1 ? 1 : 0) + (old_ ? 0 : 1);                     \
+        else if (RB_PRIO_POLICY == 7) lvl_ = (stage) == 1 ? (old_ ? 1 : 2) : 0;                           \
+        else lvl_ = (stage) == 1 ? (old_ ? 2 : 1) : 0;                                                    \
+        if (lvl_ == 0) __builtin_amdgcn_s_setprio(0);                                                     \
+        else if (lvl_ == 1) __builtin_amdgcn_s_setprio(1);                                                \
+        else __builtin_amdgcn_s_setprio(2);                                                               \
+    } while (0)
+#endif
 #ifndef RB_SPIN_LIMIT
 #define RB_SPIN_LIMIT (1 << 20)   // polls (some 0.1 s) after which a wait gives up and reports it through `fault` (common.h)
 #endif
@@ -358,9 +393,9 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
     f32x4 pacc[NSUB][NT16];  // tile n of subtile st, register i <-> output channel 16 n + 4 g + i
 
     // blk: (CH > 1) block of the launch being computed: its tiles shrink by one halo tile per block
-    auto expand = [&](int buf, int ioff, int blk = 0) {    // ioff: byte offset of the activation image to write
+    // base: LDS address of the package whose expand group is read (groups that sit in separate buffers: that group's address)
+    auto expand = [&](int base, int ioff, int blk = 0) {   // ioff: byte offset of the activation image to write
         if (we >= MTI - blk || en >= 2) return;            // wave-uniform
-        const int base = OFF_PKG + buf * PK::BYTES;
         const int w1l = base + (16 * (g4 & 1) + m16) * PK::PW1 + 16 * (g4 >> 1);
         const int pl = base + PK::OFF_B1 + 16 * g4;
 #pragma unroll
@@ -374,9 +409,9 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
             }
         }
     };
-    auto dwproject = [&](int buf, int ioff, int blk = 0) {
+    // base: LDS address the package would start at for its depthwise / project group to sit where it does
+    auto dwproject = [&](int base, int ioff, int blk = 0) {
         if (CH == 1 ? !dw_active : (we >= MTO + CH - 1 - blk || en >= 2)) return;   // wave-uniform
-        const int base = OFF_PKG + buf * PK::BYTES;
         DwStage<T, 64, NT16, PK::PW3, ST1, PITCH * SLOT, 4, NSUB> dw;
         dw.tb = tb + ioff;
         dw.set_lane(m16, g4);
@@ -393,9 +428,9 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
 #endif
     // ---- epilogue of a block in registers: x <- round((acc + x) + b3), channel for channel what the lane holds; the last
     // block of a launch also stores the image ----
-    auto block_epilogue = [&](int buf, bool store, int img) {
+    auto block_epilogue = [&](int base, bool store, int img) {
         QuadLoad<NT16> bq3;                                // b3 of channels 16 n + 4 g ..
-        bq3.issue(OFF_PKG + buf * PK::BYTES + PK::OFF_B3 + 16 * g4);
+        bq3.issue(base + PK::OFF_B3 + 16 * g4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         bq3.pin();
         // subtile st of the tile, accumulated in pacc[a]
@@ -451,6 +486,96 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
             }
             asm volatile("" ::: "memory");
         };
+#if RB_OPPOSED
+        // ROUNDS.  Round r of a wave is { depthwise + project stage of slice r, expand stage of slice r + 1 }: with two
+        // activation images (slice parity) and the package's two groups in buffers of their own, both read and write
+        // only what round r - 1 left behind, so a wave synchronises with its neighbours ONCE per round, and the order of
+        // the two inside a round is free.  The waves dispatched first (one per SIMD) expand first, the others run the
+        // depthwise stage first: the two waves of a SIMD are then in opposite stages -- matrix-heavy beside LDS- and
+        // vector-heavy -- instead of competing for the same pipe.  At the end of a block the order is fixed (the next
+        // block's expand stage needs this block's output).
+        volatile int* e_ready = exp_done + 16;             // expand groups landed
+        volatile int* d_ready = exp_done + 17;             // depthwise / project groups landed
+        constexpr int OFF_EG = OFF_PKG, OFF_DG = OFF_PKG + 2 * PK::EG_BYTES;
+        auto e_base = [&](int q) { return OFF_EG + (q & 1) * PK::EG_BYTES; };
+        auto d_base = [&](int q) { return OFF_DG + (q & 1) * PK::DG_BYTES - PK::EG_BYTES; };
+        if (wave == NW - 1) {
+            auto load_group = [&](int q, bool dgroup) {    // slice q's expand or depthwise / project group
+                const char* g = WP + (size_t)(q % npk) * PK::BYTES + (dgroup ? PK::EG_BYTES : 0) + lane * 16;
+                char* l = lds + (dgroup ? OFF_DG + (q & 1) * PK::DG_BYTES : OFF_EG + (q & 1) * PK::EG_BYTES);
+                if (dgroup) {
+#pragma unroll
+                    for (int k = 0; k < PK::DG_PIECES; ++k)
+                        __builtin_amdgcn_global_load_lds((GPTR)(g + k * 1024), (LPTR)(l + k * 1024), 16, 0, 0);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < PK::EG_PIECES; ++k)
+                        __builtin_amdgcn_global_load_lds((GPTR)(g + k * 1024), (LPTR)(l + k * 1024), 16, 0, 0);
+                }
+            };
+            load_group(0, false);
+            if (NS > 1) load_group(1, false);
+            load_group(0, true);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) { *e_ready = NS > 1 ? 2 : 1; *d_ready = 1; }
+            for (int r = 0; r < NS; ++r) {
+                // every wave has finished round r - 1: the expand group of slice r and the other group of slice r - 1 are free
+                wait_flags([&] { return lane >= MTO || (exp_done[lane & 7] >= r + 1 && dw_done[lane & 7] >= r); });
+                if (r + 2 < NS) load_group(r + 2, false);
+                if (r + 1 < NS) load_group(r + 1, true);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) { *e_ready = cmin_rt(r + 3, NS); *d_ready = cmin_rt(r + 2, NS); }
+            }
+        } else if (wave < MTO) {
+            const int nb = (lane & 1) ? wave + 1 : wave - 1;
+            const bool has_nb = nb >= 0 && nb < MTO;
+            const int nbc = has_nb ? nb : wave;
+            const bool expand_first = ((RB_EXPAND_FIRST_WAVES) >> wave) & 1;   // wave-uniform
+            auto do_expand = [&](int q) {                  // slice q: its image's first slice loads the image
+                if (q % npk == 0) load_x((int)blockIdx.y + (q / npk) * (int)gridDim.y);
+                RB_T(ta);
+                expand(e_base(q), (q & 1) * ES_BYTES);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the rows are in LDS before the flag goes up
+                if (lane == 0) exp_done[wave] = q + 1;
+                RB_T(tb_);
+                RB_ACC(0, ta, tb_);
+            };
+#pragma unroll 1
+            for (int r = -1; r < NS; ++r) {
+                const bool has_next = r + 1 < NS;
+                const int c = r < 0 ? NCH - 1 : r % NCH;
+                const bool block_end = c == NCH - 1;
+                RB_T(t0);
+                // what round r - 1 left: the neighbours' rows of slice r, their reads of slice r - 1's rows; this round's groups
+                wait_flags([&] {
+                    return *e_ready >= cmin_rt(r + 2, NS) && *d_ready >= r + 1 &&
+                           (!has_nb || (exp_done[nbc] >= r + 1 && dw_done[nbc] >= r));
+                });
+                RB_T(t1);
+                RB_ACC(1, t0, t1);
+                const bool first = expand_first && !block_end && has_next;
+                if (first) do_expand(r + 1);
+                if (r >= 0) {
+                    if (c == 0) {
+#pragma unroll
+                        for (int st = 0; st < NSUB; ++st)
+#pragma unroll
+                            for (int n = 0; n < NT16; ++n) pacc[st][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    RB_T(t3);
+                    dwproject(d_base(r), (r & 1) * ES_BYTES);
+                    RB_T(t4);
+                    RB_ACC(2, t3, t4);
+                    if (block_end) block_epilogue(d_base(r), (r / NCH) % nblk == nblk - 1, (int)blockIdx.y + (r / npk) * (int)gridDim.y);
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) dw_done[wave] = r + 1;                      // every read of image and package has returned
+                    RB_T(t5);
+                    RB_ACC(4, t4, t5);
+                }
+                if (has_next && !first) do_expand(r + 1);
+            }
+        }
+#else
         if (wave == NW - 1) {
             // ---- loader: package s goes into buffer s & 1 once every wave has finished reading slice s - 2 ----
             // (loading the half the expand stage reads as soon as every wave has expanded slice s - 2, with a flag of
@@ -487,7 +612,8 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
                         wait_flags([&] { return *pkg_ready >= s + 1 && (!has_nb || dw_done[nbc] >= s - 1); });
                         RB_T(t1);
                         RB_ACC(1, t0, t1);
-                        expand(buf, ioff);
+                        RB_PRIO_STAGE(0);
+                        expand(OFF_PKG + buf * PK::BYTES, ioff);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the rows are in LDS before the flag goes up
                         if (lane == 0) exp_done[wave] = s + 1;
                         RB_T(t2);
@@ -495,10 +621,11 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
                         wait_flags([&] { return !has_nb || exp_done[nbc] >= s + 1; });
                         RB_T(t3);
                         RB_ACC(3, t2, t3);
-                        dwproject(buf, ioff);
+                        RB_PRIO_STAGE(1);
+                        dwproject(OFF_PKG + buf * PK::BYTES, ioff);
                         RB_T(t4);
                         RB_ACC(2, t3, t4);
-                        if (c == NCH - 1) block_epilogue(buf, b == nblk - 1, img);   // reads b3 from the package
+                        if (c == NCH - 1) block_epilogue(OFF_PKG + buf * PK::BYTES, b == nblk - 1, img);   // reads b3 from the package
                         asm volatile("" ::: "memory");
                         if (lane == 0) dw_done[wave] = s + 1;                  // every read of image and package has returned
                         RB_T(t5);
@@ -507,6 +634,7 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
                 }
             }
         }
+#endif
     } else {
     // A workgroup keeps its band and walks over images blockIdx.y, blockIdx.y + gridDim.y, ...
     for (int img = blockIdx.y; img < B; img += gridDim.y) {
@@ -536,7 +664,7 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
                 RB_T(t0);
                 RB_ACC(5, ts, t0);
 #ifndef RB_ABL_NO_EXPAND
-                expand(buf, 0, blk);
+                expand(OFF_PKG + buf * PK::BYTES, 0, blk);
 #endif
                 RB_T(t1);
                 RB_ACC(0, t0, t1);
@@ -549,12 +677,12 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
                 RB_T(t2);
                 RB_ACC(1, t1, t2);
 #ifndef RB_ABL_NO_DW
-                dwproject(buf, 0, blk);
+                dwproject(OFF_PKG + buf * PK::BYTES, 0, blk);
 #endif
                 RB_T(t3);
                 RB_ACC(2, t2, t3);
                 const bool dwa = CH == 1 ? dw_active : (we < MTO + CH - 1 - blk && en < 2);      // wave-uniform
-                if (c == NCH - 1 && dwa) block_epilogue(buf, b == nblk - 1, img);
+                if (c == NCH - 1 && dwa) block_epilogue(OFF_PKG + buf * PK::BYTES, b == nblk - 1, img);
                 if constexpr (CH > 1) {
                     // the block's output for the next block's expand stage: this wave holds ITS subtile of the tile, the
                     // wave it shares the tile with the other one
