@@ -75,10 +75,44 @@ def test_harness_against_oracle(hip_model_calibrated, device, calibrated_state_d
               (oacc.mean() * 100, othr.mean(), at_ref.mean() * 100))
         assert abs(at_ref.mean() - oacc.mean()) * 100 <= 0.1 + 1e-9
         # each side's OWN threshold is the mean of a plateau of equally good grid points and can jump when a tie
-        # between plateaus breaks, taking test accuracy with it: reported above, bounded loosely here
+        # between plateaus breaks, taking test accuracy with it; on these hard, small phases (94-95 %, one pair = 0.1 pt)
+        # that is measured at 0.0 - 0.3 pt (three pairs) and bounded at 0.5 here -- the 0.1-pt bar with each side's own
+        # thresholds is asserted at LFW's size and difficulty in test_reference_protocol_at_lfw_size_and_difficulty
         assert abs(float(m.group(2)) - oacc.mean() * 100) <= 0.5
         assert abs(float(m.group(3)) - othr.mean()) < 0.05
         assert abs(res[phase][0].mean() * 100 - float(m.group(2))) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weights", ["calibrated", "uncalibrated"])
+def test_reference_protocol_at_lfw_size_and_difficulty(weights, request, device):
+    """The reference's protocol as it stands -- thresholds searched on each side, nothing injected -- on a phase of LFW's
+    real size (6000 pairs, folds of 600: one pair is 0.017 pt) and LFW's real difficulty for this network (pair noise 0.30:
+    the fp32 oracle scores 99.3-99.4 %): the harness's printed accuracy within 0.1 pt of the oracle's.
+    Measured: -0.05 pt with calibrated final-BatchNorm statistics, 0.00 pt with the arbitrary ones of the seeded weights
+    (whose embeddings cluster; the threshold moves by 0.0005 there).  On HARDER synthetic sets (noise 0.45, the oracle at
+    93.4-94.6 %, ten times as many pairs next to the threshold) the same comparison measures -0.12 .. +0.04 pt at 6000 -
+    8400 pairs and up to +-0.15 pt at 2000: that figure is recorded, not asserted at 0.1 -- a threshold that is the mean of
+    a plateau of equally good grid points moves when one pair's score moves by 0.0006, whatever computed it
+    (scripts/diag/own_threshold_delta.py prints all of these)."""
+    from oracle import evaluation_ref, mobilefacenet_ref
+    sd = request.getfixturevalue("calibrated_state_dict_np" if weights == "calibrated" else "state_dict_np")
+    model = request.getfixturevalue("hip_model_calibrated" if weights == "calibrated" else "hip_model")
+    sizes = {"LFW": 6000}
+    out = io.StringIO()
+    res = harness.run(model, device, batch_size=50, sizes=sizes, seed=5, noise=0.30, out=out)
+    m = re.match(r"Epoch 1/1，LFW average acc:([\d.]+) average threshold:(-?[\d.]+)", out.getvalue().strip())
+    assert m, out.getvalue()
+    _, _, sets = harness.load_test_data(50, sizes=sizes, seed=5, noise=0.30, device=device)
+    ds = sets["LFW"]
+    cpu_batches = ([t.cpu() for t in b] for b in harness.PairLoader(ds, 200))
+    ol, orr = evaluation_ref.get_feature(lambda x: mobilefacenet_ref.forward(sd, x), cpu_batches, flip=True)
+    oacc, othr = evaluation_ref.evaluation_10_fold(ol.numpy(), orr.numpy(), ds.folds, ds.flags, "cos_distance")
+    print("%s: harness %s / %s | oracle %.4f / %.4f" % (weights, m.group(1), m.group(2), oacc.mean() * 100, othr.mean()))
+    assert oacc.mean() > 0.985                                              # the set is as easy as the real one
+    assert abs(float(m.group(1)) - oacc.mean() * 100) <= 0.1 + 1e-9
+    assert abs(res["LFW"][0].mean() * 100 - oacc.mean() * 100) <= 0.1 + 1e-9
+    assert abs(float(m.group(2)) - othr.mean()) < 0.005
 
 
 @pytest.mark.gpu
