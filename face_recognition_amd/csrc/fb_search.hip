@@ -219,6 +219,13 @@ __device__ __forceinline__ void fold_chain(Ctx& c, int row0, int rt) {
     }
 }
 
+// -DSEARCH_PRIO=n (experiments): issue priority inside a step.  1: raised while a wave requests its staging piece;
+// 2: raised for the waves dispatched second (4-7) throughout;  3: raised around the matrix instructions of a step;
+// 4: raised during the list update.  10k queries x 1M / 8M rows, one box, ms: 0: 8.20-8.21 / 58.7-58.8,  1: 8.25 / 58.9,
+// 2: 8.16 / 58.6,  3: 8.36 / 59.7,  4: 8.21 / 58.7 -- nothing outside the run-to-run spread, none adopted
+#ifndef SEARCH_PRIO
+#define SEARCH_PRIO 0
+#endif
 template <typename T, int KS, int NB, int QTW, int S> struct SearchSteps {
     typedef typename vec8<T>::type V8;
     typedef SearchCtx<T, KS, NB, QTW> Ctx;
@@ -269,6 +276,7 @@ template <typename T, int KS, int NB, int QTW, int S> struct SearchSteps {
         if constexpr (S < SEARCH_STEPS) {
             constexpr int rt = S / SEARCH_KSTEPS, ks = S % SEARCH_KSTEPS, slot = S % NB;
             read_step<S + PD>(c);
+            if (SEARCH_PRIO == 3) __builtin_amdgcn_s_setprio(1);
             if constexpr (ks == 0) {
                 // wait for this step's fragment and the chain's bias; both are named so that their
                 // consumers cannot be moved above the wait
@@ -280,10 +288,17 @@ template <typename T, int KS, int NB, int QTW, int S> struct SearchSteps {
 #pragma unroll
                 for (int u = 0; u < QTW; ++u) MMA::next(c.acc[rt][u], c.af[slot], c.qf[ks][u]);
             }
-            if constexpr (S % GEO::PIECE_EVERY == GEO::PIECE_AT && S / GEO::PIECE_EVERY < GEO::PIECES) stage_piece<S / GEO::PIECE_EVERY>(c);
-            if constexpr (ks == 2) {   // the previous chain finished two steps ago: fold it in under this chain
+            if (SEARCH_PRIO == 3) __builtin_amdgcn_s_setprio(0);
+            if constexpr (S % GEO::PIECE_EVERY == GEO::PIECE_AT && S / GEO::PIECE_EVERY < GEO::PIECES) {
+                if (SEARCH_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+                stage_piece<S / GEO::PIECE_EVERY>(c);
+                if (SEARCH_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+            }
+            if constexpr (ks == 2) {
+                if (SEARCH_PRIO == 4) __builtin_amdgcn_s_setprio(1);   // the previous chain finished two steps ago: fold it in under this chain
                 if constexpr (rt == 0) { if (have_prev) fold_chain<Ctx, KS, QTW>(c, row0 - BG, SEARCH_CHAINS - 1); }
                 else fold_chain<Ctx, KS, QTW>(c, row0, rt - 1);
+                if (SEARCH_PRIO == 4) __builtin_amdgcn_s_setprio(0);
             }
             if constexpr (S == BARRIER_STEP) {
                 // tile barrier, just before the first read of the next tile: this wave's pieces of the
@@ -375,6 +390,7 @@ __device__ __forceinline__ void search_body(const T* __restrict__ G, const float
     }
     __syncthreads();   // drains the loads above
 
+    if (SEARCH_PRIO == 2 && wave >= GEO::NWV / 2) __builtin_amdgcn_s_setprio(1);
     if (t_begin < t_end) {
         int cur = 0;   // buffer of tile t; t + 1 sits in cur + 1, t + 2 is staged into cur + 2 (mod 3)
 #pragma unroll
