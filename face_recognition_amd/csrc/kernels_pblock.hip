@@ -61,6 +61,12 @@ extern "C" int fra_dbg_read(void* dst, size_t bytes) {
 #define PB_ACC(i, a, b)
 #endif
 
+// -DPB_PRIO=n (experiments): issue priority by role.  1: consumer waves raised throughout;  2: producer waves raised
+// throughout;  3: a consumer raised for its depthwise + project stage only;  4: as 3, and a producer raised for its
+// expand stage (not while it polls or loads)
+#ifndef PB_PRIO
+#define PB_PRIO 0
+#endif
 #ifndef PB_SPIN_LIMIT
 #define PB_SPIN_LIMIT (1 << 20)   // polls (some 0.1 s) after which a wait gives up and reports it through `fault` (common.h)
 #endif
@@ -183,6 +189,7 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
         asm volatile("" ::: "memory");
         PB_T(t1);
         PB_ACC(0, t0, t1);
+        if (PB_PRIO == 4) __builtin_amdgcn_s_setprio(1);
         static_for<NCH>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             static_for<2>([&](auto ntc) {
@@ -212,6 +219,7 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
             });
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the tile is in LDS before its flag goes up
+        if (PB_PRIO == 4) __builtin_amdgcn_s_setprio(0);
         if (lane == 0) ready[t % NTF] = t + 1;
         PB_T(t2);
         PB_ACC(1, t1, t2);
@@ -279,6 +287,7 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
         for (int st = 0; st < 2; ++st)
 #pragma unroll
             for (int n = 0; n < NT16; ++n) pacc[st][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (PB_PRIO >= 3) __builtin_amdgcn_s_setprio(1);
         static_for<NCH>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             DwStage<T, CEXP, NT16, PW3, 0, 0, 4, 2, true> dw;
@@ -295,6 +304,7 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
             dw.run(pacc);
         });
         asm volatile("" ::: "memory");
+        if (PB_PRIO >= 3) __builtin_amdgcn_s_setprio(0);
         if (lane == 0) progress[cw] = t;                   // every read of the windows has returned
         PB_T(t2);
         PB_ACC(4, t1, t2);
@@ -315,6 +325,8 @@ void pblock_kernel(const T* __restrict__ X, const T* __restrict__ W1, const floa
     };
 
     // fixed roles: waves 0 .. NP-1 produce tiles p, p + NP, ..., the others consume tiles c, c + NC, ...
+    if (PB_PRIO == 1 && wave >= NP) __builtin_amdgcn_s_setprio(1);
+    if (PB_PRIO == 2 && wave < NP) __builtin_amdgcn_s_setprio(1);
     if (wave < NP) {
         if (wave < NTL) load_tile(xf, wave);
         for (int t = wave; t < NTL; t += NP) produce(t, t + NP);
