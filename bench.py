@@ -415,6 +415,8 @@ def latency(net, dev):
         out[f"b{B}"] = {"eager_forward": timeit(net, x, 300, 30),
                         "eager_forward_match": timeit(lambda t: match_facebank(net(t), bank, 60), x, 300, 30),
                         "graph_forward_match": timeit(rec, x),
+                        # the crops written straight into the graph's input (a per-frame loop's H2D copy lands there)
+                        "graph_forward_match_static_input": timeit(rec, rec.input_buffer(B).copy_(x)),
                         "graph_forward_match_bank5": timeit(rec5, x),
                         "graph_tta_forward_match": timeit(rec_tta, x)}
     return out

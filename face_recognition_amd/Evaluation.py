@@ -71,11 +71,16 @@ def getFeature(net, dataloader, device, flip=True, keep_on_device=False, group_c
     ``group_crops`` (not in the reference): consecutive loader batches go through ONE forward as long as
     they hold at most that many crops together (the reference harness's batch size 50 is 200 crops per
     forward, a quarter of what fills the chip).  A row of the output does not depend on the batch it was
-    computed in -- bit for bit, for a network that says so (``net.batch_invariant``) -- so the features are
-    the ones a forward per loader batch gives.  Default: 1024 for such a network, else 0 = one forward per
-    loader batch, as the reference does."""
+    computed in -- bit for bit, for a network that says so (``net.batch_invariant``, or from
+    ``net.batch_invariant_from()`` crops on) -- so the features are the ones a forward per loader batch gives:
+    a loader batch below that size goes through a forward of its own.  Default: 1024 for such a network, else
+    0 = one forward per loader batch, as the reference does."""
+    invariant = bool(getattr(net, "batch_invariant", False))
+    min_group = 1 if invariant else (net.batch_invariant_from(device) if hasattr(net, "batch_invariant_from") else None)
     if group_crops is None:
-        group_crops = 1024 if getattr(net, "batch_invariant", False) else 0
+        group_crops = 1024 if min_group is not None else 0
+    if min_group is None:
+        min_group = 1
     featureLs, featureRs = [], []
     pending, pending_crops = [], 0
 
@@ -98,11 +103,15 @@ def getFeature(net, dataloader, device, flip=True, keep_on_device=False, group_c
     for det in dataloader:
         det = [d.to(device, non_blocking=True) for d in det]
         n = sum(d.size(0) for d in det)
-        if pending and pending_crops + n > group_crops:
+        alone = n < min_group                              # too small to share a forward without changing its bits
+        if pending and (alone or pending_crops + n > group_crops):
             flush()
             pending_crops = 0
         pending.append(det)
         pending_crops += n
+        if alone:
+            flush()
+            pending_crops = 0
     if pending:
         flush()
     if not featureLs:

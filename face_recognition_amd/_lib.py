@@ -29,6 +29,8 @@ SIGNATURES = {
     "fra_version": (_I, []),
     "fra_device_fault": (_I, [_I, C.POINTER(C.c_uint)]),
     "fra_dbg_set_spin_limit": (_I, [_I]),
+    "fra_set_small_batch_mode": (_I, [_I]),
+    "fra_get_small_batch_mode": (_I, []),
     "fra_dbg_alloc_calls": (C.c_long, []),
     "mfn_create": (_I, [C.POINTER(_P), _I, _I, _I]),
     "mfn_load_weights": (_I, [_P, C.POINTER(TensorDesc), _I]),

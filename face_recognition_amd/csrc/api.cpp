@@ -84,6 +84,10 @@ int check_device_fault(int device) {
     return FRA_ERR_STATE;
 }
 
+static std::atomic<int> g_small_batch_mode{1};
+int small_batch_mode() { return g_small_batch_mode.load(std::memory_order_relaxed); }
+void set_small_batch_mode(int mode) { g_small_batch_mode.store(mode, std::memory_order_relaxed); }
+
 }  // namespace fra
 
 extern "C" {
@@ -94,6 +98,15 @@ int fra_device_fault(int device, unsigned* tag_out) {
     if (tag_out) *tag_out = tag;
     return tag ? FRA_ERR_STATE : FRA_OK;
 }
+int fra_set_small_batch_mode(int mode) {
+    if (mode != 0 && mode != 1) {
+        fra::set_error("fra_set_small_batch_mode: mode %d (0 = batch-invariant bits, 1 = shortest small-batch launches)", mode);
+        return FRA_ERR_ARG;
+    }
+    fra::set_small_batch_mode(mode);
+    return FRA_OK;
+}
+int fra_get_small_batch_mode(void) { return fra::small_batch_mode(); }
 long fra_dbg_alloc_calls(void) { return fra::alloc_calls(); }
 int fra_dbg_set_spin_limit(int polls) {
     fra::g_spin_limit.store(polls, std::memory_order_relaxed);

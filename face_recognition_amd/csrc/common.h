@@ -230,6 +230,11 @@ int pack_rblock(int dt, int c, int cexp, const float* w1, const float* b1, const
 int launch_rblock(int dt, int c, int cexp, int h, const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s);
 // the same chain as four wide waves per workgroup, one per SIMD (kernels_wblock.hip): same packages, same results bit
 // for bit; wblock_has(): the shapes it is built for
+// 0: every batch size runs the same arithmetic per output value (a face's embedding does not depend on the batch it is
+// computed in, bit for bit); 1 (default): batches whose band launches fit the chip in one go (7 B <= compute units) add a
+// block's project sum in two halves (kernels_rblock.hip, dual slices) -- shorter launches, the same values to rounding
+int small_batch_mode();
+void set_small_batch_mode(int mode);
 bool wblock_has(int c, int cexp, int h);
 int launch_wblock(int dt, int c, int cexp, int h, const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s);
 // true when `nblk` > 1 blocks of this shape should run as one launch for a batch of B images

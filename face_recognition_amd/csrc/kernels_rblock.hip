@@ -181,6 +181,17 @@ extern "C" int fra_dbg_read(void* dst, size_t bytes) {
 // above and below (from CH more input rows each side), the next on one row less each side, ...: no row ever comes from
 // another workgroup, at the price of computing the rows next to a band twice -- which costs a small batch nothing, while
 // every launch it saves is some 9 microseconds.
+// DUAL SLICES (CH > 1, DUAL; small_batch_mode() == 1, the default, selects it).  A band workgroup of a small batch has three input tiles and two output tiles for eight waves, and
+// a slice is a chain of latencies -- package, expand stage, barrier, depthwise + project stage, barrier -- that its little
+// work does not fill.  So slices 2 r and 2 r + 1 of a block run in the same round: every expand wave expands its
+// channel tiles of BOTH slices into two activation images, then the depthwise + project work of slice 2 r goes to the
+// waves of tiles 0 and 1 and that of slice 2 r + 1 to the waves that would otherwise wait (tiles 2 and 3 of the expand
+// side), each with project sums of its own.  At the end of a block the second set of sums is handed over through LDS and
+// added to the first: x <- round(((even slices + odd slices) + x) + b3) -- the project sum is associated differently from
+// the one-slice-at-a-time kernels, so batches that run here (7 B <= compute units) agree with larger batches to rounding,
+// not bit for bit; among themselves they agree bit for bit.  The two groups of a package (RbPkg) have buffers of their own
+// per slice of the round: the expand groups of round r + 1 arrive during the depthwise stage of round r, the depthwise /
+// project groups of round r during its expand stage.
 template <int H, int TR, int G, int CH = 1> constexpr int rb_es_bytes() {
     return G > 1 ? G * 64 * 144 : (TR + 2 * CH) * block_pitch<H, 1>() * 144;
 }
@@ -193,16 +204,16 @@ template <int H, int TR, int G> constexpr int rb_main_tiles() {
 template <int H, int TR, int NW, int G> constexpr bool rb_flags() {
     return TR == H && RB_FLAGS && rb_main_tiles<H, TR, G>() > NW / 2 && rb_main_tiles<H, TR, G>() < NW;
 }
-template <int H, int TR, int NW, int G, int CH = 1> constexpr int rb_images_bytes() {
+template <int H, int TR, int NW, int G, int CH = 1, bool DUAL = false> constexpr int rb_images_bytes() {
     return G > 1 ? (2 * rb_es_bytes<H, TR, G>() + 16 * 144 + 1023) / 1024 * 1024
-                 : (rb_flags<H, TR, NW, G>() ? 2 : 1) * rb_es_bytes<H, TR, G, CH>();
+                 : (rb_flags<H, TR, NW, G>() || DUAL ? 2 : 1) * rb_es_bytes<H, TR, G, CH>();
 }
-template <int C, int CEXP, int H, int TR, int NW, int G = 1, int CH = 1> constexpr int rblock_lds_bytes() {
-    return rb_images_bytes<H, TR, NW, G, CH>() + 2 * RbPkg<C>::BYTES + (rb_flags<H, TR, NW, G>() ? 128 : 0) +
-           (CH > 1 ? (rb_main_tiles<H, TR, G>() + CH - 1) * 2 * 64 * (C / 32) * 16 : 0);
+template <int C, int CEXP, int H, int TR, int NW, int G = 1, int CH = 1, bool DUAL = false> constexpr int rblock_lds_bytes() {
+    return rb_images_bytes<H, TR, NW, G, CH, DUAL>() + 2 * RbPkg<C>::BYTES + (rb_flags<H, TR, NW, G>() ? 128 : 0) +
+           (CH > 1 ? (rb_main_tiles<H, TR, G>() + CH - 1) * 2 * 64 * (DUAL ? C / 16 : C / 32) * 16 : 0);
 }
 
-template <typename T, int C, int CEXP, int H, int TR, int NW, int G, int CH>
+template <typename T, int C, int CEXP, int H, int TR, int NW, int G, int CH, bool DUAL>
 __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk,
                                             unsigned* __restrict__ fault, int spin_limit);
 
@@ -210,19 +221,19 @@ template <typename T, int C, int CEXP, int H, int TR, int NW, int G = 1, int CH 
 __global__ __launch_bounds__(NW * 64, 2)
 void rblock_kernel(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk,
                    unsigned* __restrict__ fault, int spin_limit) {
-    rblock_body<T, C, CEXP, H, TR, NW, G, CH>(X, WP, O, B, nblk, fault, spin_limit);
+    rblock_body<T, C, CEXP, H, TR, NW, G, CH, false>(X, WP, O, B, nblk, fault, spin_limit);
 }
 
 // the same body with the register budget of exactly two waves per SIMD spelled out (the several-blocks-per-band
 // configuration: left to itself the compiler aims at three waves and spills)
-template <typename T, int C, int CEXP, int H, int TR, int NW, int G, int CH>
+template <typename T, int C, int CEXP, int H, int TR, int NW, int G, int CH, bool DUAL>
 __global__ __launch_bounds__(NW * 64, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void rblock_kernel_w2(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk,
                       unsigned* __restrict__ fault, int spin_limit) {
-    rblock_body<T, C, CEXP, H, TR, NW, G, CH>(X, WP, O, B, nblk, fault, spin_limit);
+    rblock_body<T, C, CEXP, H, TR, NW, G, CH, DUAL>(X, WP, O, B, nblk, fault, spin_limit);
 }
 
-template <typename T, int C, int CEXP, int H, int TR, int NW, int G, int CH>
+template <typename T, int C, int CEXP, int H, int TR, int NW, int G, int CH, bool DUAL>
 __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char* __restrict__ WP, T* __restrict__ O, int B, int nblk,
                                             unsigned* __restrict__ fault, int spin_limit) {
     typedef typename vec8<T>::type V8;
@@ -253,12 +264,16 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
     // one.  The tile-less last wave copies the weight packages and tells the others when one has landed.
     constexpr bool FL = rb_flags<H, TR, NW, G>();
     constexpr int NIMG = FL ? 2 : 1;
-    constexpr int IMG_BYTES = rb_images_bytes<H, TR, NW, G, CH>();
+    constexpr int IMG_BYTES = rb_images_bytes<H, TR, NW, G, CH, DUAL>();
     constexpr int OFF_PKG = IMG_BYTES, OFF_FLAGS = OFF_PKG + 2 * PK::BYTES;
     static_assert(!STACK || (FL && H == 7 && (G == 2 || G == 4)), "stacked images: 7 x 7 maps, whole-image workgroups with flags");
     static_assert(IMG_BYTES >= NIMG * ES_BYTES, "both activation images fit");
     constexpr int OFF_XCH = OFF_FLAGS + (FL ? 128 : 0);
-    constexpr int XCH_BYTES = CH > 1 ? (MTO + CH - 1) * 2 * 64 * KS * 16 : 0;   // per output tile and subtile: a lane's KS fragments
+    constexpr bool DS = DUAL;
+    static_assert(!DUAL || CH > 1, "dual slices are a mode of the several-blocks-per-band launches");
+    // per output tile and subtile: a lane's KS fragments (DS: first the NT16 quads of the odd slices' project sums)
+    constexpr int XCH_SLOT = 64 * (DS ? NT16 : KS) * 16;
+    constexpr int XCH_BYTES = CH > 1 ? (MTO + CH - 1) * 2 * XCH_SLOT : 0;
     constexpr int LDS_BYTES = OFF_XCH + XCH_BYTES;
     constexpr int MTIW = (MTI + NW - 1) / NW;              // input tiles per wave
     // with at most NW / 2 input tiles two waves share one and expand two of the slice's four channel tiles each
@@ -273,7 +288,7 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
     static_assert(CH == 1 || SSPLIT, "several blocks per band launch: two waves per tile, a subtile each");
     constexpr int NSUB = SSPLIT ? 1 : 2;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static_assert(LDS_BYTES == rblock_lds_bytes<C, CEXP, H, TR, NW, G, CH>(), "the launcher's LDS size is this map's");
+    static_assert(LDS_BYTES == rblock_lds_bytes<C, CEXP, H, TR, NW, G, CH, DUAL>(), "the launcher's LDS size is this map's");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -293,7 +308,7 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
                 __builtin_amdgcn_global_load_lds((GPTR)(g + k * 1024), (LPTR)(l + k * 1024), 16, 0, 0);
         }
     };
-    if constexpr (!FL) stage(0, 0);
+    if constexpr (!FL && !DS) stage(0, 0);
 #ifdef RB_PRIO_YOUNG
     if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses issue arbitration otherwise
 #endif
@@ -370,7 +385,10 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
     };
 
     // ---- depthwise / project side: wave wt owns output tile wt (its own main input tile), or one subtile of it --
-    const int wt = SSPLIT ? we : wave;
+    // (DS) tiles 0 and 1 are output tiles; the waves of expand tiles 2 and 3 take the same two tiles for the round's odd slice
+    static_assert(!DS || (MTO == 1 && CH == 2 && MTIP == 4 && NW == 8 && NCH % 2 == 0), "dual slices: one main tile, two blocks, eight waves");
+    const int wt = DS ? (we & 1) : (SSPLIT ? we : wave);
+    const int dpar = DS ? (we >> 1) : 0;                   // (DS) which slice of a round this wave's depthwise + project stage works on
     const bool dw_active = SSPLIT ? (we < MTO && en < 2) : (wt < MTO);
     constexpr int ST1 = STACK ? GP * 64 * SLOT : (POW == 32 ? 16 * SLOT : (16 / POW) * PITCH * SLOT);
     static_assert(ST1 + 2 * PITCH * SLOT + 112 < 65536, "tap offsets must fit the instruction's offset field");
@@ -411,7 +429,7 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
     };
     // base: LDS address the package would start at for its depthwise / project group to sit where it does
     auto dwproject = [&](int base, int ioff, int blk = 0) {
-        if (CH == 1 ? !dw_active : (we >= MTO + CH - 1 - blk || en >= 2)) return;   // wave-uniform
+        if (CH == 1 ? !dw_active : (wt >= MTO + CH - 1 - blk || en >= 2)) return;   // wave-uniform
         DwStage<T, 64, NT16, PK::PW3, ST1, PITCH * SLOT, 4, NSUB> dw;
         dw.tb = tb + ioff;
         dw.set_lane(m16, g4);
@@ -635,6 +653,111 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
             }
         }
 #endif
+    } else if constexpr (DS) {
+    // ================= bands of small batches, two slices per round (DUAL SLICES above) =================
+    constexpr int NRD = NCH / 2;
+    constexpr int OFF_EG = OFF_PKG, OFF_DG = OFF_PKG + 2 * PK::EG_BYTES;
+    static_assert(OFF_DG + 2 * PK::DG_BYTES == OFF_PKG + 2 * PK::BYTES, "the two packages' groups fill the two package buffers");
+    // group `dgroup` of package p into the buffer of the round's slice `par`; piece k is copied by wave k % NW
+    auto stage_group = [&](int p, int par, bool dgroup) {
+        const char* g = WP + (size_t)p * PK::BYTES + (dgroup ? PK::EG_BYTES : 0) + lane * 16;
+        char* l = lds + (dgroup ? OFF_DG + par * PK::DG_BYTES : OFF_EG + par * PK::EG_BYTES);
+        const int pieces = dgroup ? PK::DG_PIECES : PK::EG_PIECES;
+#pragma unroll
+        for (int j = 0; j < (cmax(PK::DG_PIECES, PK::EG_PIECES) + NW - 1) / NW; ++j) {
+            const int k = wave + NW * j;
+            if (k < pieces)                                // wave-uniform
+                __builtin_amdgcn_global_load_lds((GPTR)(g + k * 1024), (LPTR)(l + k * 1024), 16, 0, 0);
+        }
+    };
+    const int e_base0 = OFF_EG, e_base1 = OFF_EG + PK::EG_BYTES;
+    const int d_base = OFF_DG + dpar * PK::DG_BYTES - PK::EG_BYTES;    // where this wave's slice's package would start
+    char* const xslot = lds + OFF_XCH + (wt * 2 + en) * XCH_SLOT;        // this (tile, subtile)'s hand-over slot
+    stage_group(0, 0, false);
+    stage_group(1, 1, false);
+    for (int img = blockIdx.y; img < B; img += gridDim.y) {
+        const bool has_next = img + (int)gridDim.y < B;
+        load_x(img);
+        if (img == (int)blockIdx.y) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // expand groups of packages 0 and 1 (later images: requested in the image before)
+            __syncthreads();                                   // ... and the zeroed images
+        }
+        int p = 0;                                             // package of the round's even slice
+#pragma unroll 1
+        for (int b = 0; b < nblk; ++b) {
+            const int blk = b;
+#pragma unroll
+            for (int n = 0; n < NT16; ++n) pacc[0][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool dwa = wt < MTO + CH - 1 - blk;          // wave-uniform: this wave has depthwise / project work in this block
+#pragma unroll 1
+            for (int r = 0; r < NRD; ++r, p += 2) {
+                RB_T(ts);
+                // this round's depthwise / project groups: their buffers were last read before the previous round's last barrier
+                stage_group(p, 0, true);
+                stage_group(p + 1, 1, true);
+                RB_T(t0);
+                RB_ACC(5, ts, t0);
+                expand(e_base0, 0, blk);
+                expand(e_base1, ES_BYTES, blk);
+                RB_T(t1);
+                RB_ACC(0, t0, t1);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // both images written, both groups landed
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                RB_T(t2);
+                RB_ACC(1, t1, t2);
+                // the next round's expand groups (this round's have been read)
+                const int pn = p + 2 < npk ? p + 2 : (has_next ? 0 : -1);
+                if (pn >= 0) {
+                    stage_group(pn, 0, false);
+                    stage_group(pn + 1, 1, false);
+                }
+                dwproject(d_base, dpar * ES_BYTES, blk);
+                RB_T(t3);
+                RB_ACC(2, t2, t3);
+                const bool block_end = r == NRD - 1;
+                if (block_end && dwa && dpar == 1) {           // the odd slices' sums go to the wave that holds the tile's activation
+#pragma unroll
+                    for (int n = 0; n < NT16; ++n) *reinterpret_cast<f32x4*>(xslot + (n * 64 + lane) * 16) = pacc[0][n];
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                RB_T(t4);
+                RB_ACC(3, t3, t4);
+                __syncthreads();                               // images free, the next expand groups visible, hand-over written
+                if (block_end) {
+                    if (dwa && dpar == 0) {
+#pragma unroll
+                        for (int n = 0; n < NT16; ++n) {
+                            const f32x4 o = *reinterpret_cast<const f32x4*>(xslot + (n * 64 + lane) * 16);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) pacc[0][n][i] += o[i];
+                        }
+                        block_epilogue(d_base, b == nblk - 1, img);            // reads b3 from the even slice's package
+                        if (b + 1 < nblk) {                                    // this subtile's new activation for the wave it shares the tile with
+#pragma unroll
+                            for (int ks = 0; ks < KS; ++ks) {
+                                if (en) *reinterpret_cast<V8*>(xslot + (ks * 64 + lane) * 16) = xf[0][1][ks];   // wave-uniform
+                                else *reinterpret_cast<V8*>(xslot + (ks * 64 + lane) * 16) = xf[0][0][ks];
+                            }
+                        }
+                    }
+                    __syncthreads();                           // b3 read before the next round's groups arrive; hand-over of x written
+                    if (b + 1 < nblk && dwa && dpar == 0) {
+                        const char* xi = lds + OFF_XCH + (wt * 2 + (en ^ 1)) * XCH_SLOT;
+                        if (en) {
+#pragma unroll
+                            for (int ks = 0; ks < KS; ++ks) xf[0][0][ks] = *reinterpret_cast<const V8*>(xi + (ks * 64 + lane) * 16);
+                        } else {
+#pragma unroll
+                            for (int ks = 0; ks < KS; ++ks) xf[0][1][ks] = *reinterpret_cast<const V8*>(xi + (ks * 64 + lane) * 16);
+                        }
+                    }
+                }
+                RB_T(t5);
+                RB_ACC(4, t4, t5);
+            }
+        }
+    }
     } else {
     // A workgroup keeps its band and walks over images blockIdx.y, blockIdx.y + gridDim.y, ...
     for (int img = blockIdx.y; img < B; img += gridDim.y) {
@@ -747,15 +870,15 @@ static int rb_compute_units() {
     return cus;
 }
 
-template <typename T, int C, int CEXP, int H, int TR, int NW, int G = 1, int CH = 1>
+template <typename T, int C, int CEXP, int H, int TR, int NW, int G = 1, int CH = 1, bool DUAL = false>
 static int launch_rblock_cfg(const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s) {
     constexpr int bands = H / TR;
-    constexpr int lds = rblock_lds_bytes<C, CEXP, H, TR, NW, G, CH>();
+    constexpr int lds = rblock_lds_bytes<C, CEXP, H, TR, NW, G, CH, DUAL>();
     FRA_REQUIRE(CH > 1 ? nblk == CH : (nblk == 1 || (TR == H && rb_main_tiles<H, TR, G>() > NW / 2)), FRA_ERR_ARG,
                 "rblock: %d blocks per launch need whole-image workgroups with a tile per wave", nblk);
     static_assert(G == 1 || rb_flags<H, TR, NW, G>(), "stacked images run on the flag-synchronised loop");
     void (*kern)(const T*, const char*, T*, int, int, unsigned*, int);
-    if constexpr (CH > 1) kern = rblock_kernel_w2<T, C, CEXP, H, TR, NW, G, CH>;
+    if constexpr (CH > 1) kern = rblock_kernel_w2<T, C, CEXP, H, TR, NW, G, CH, DUAL>;
     else kern = rblock_kernel<T, C, CEXP, H, TR, NW, G, CH>;
     static std::atomic<uint64_t> lds_set;      // per instantiation: devices whose LDS limit is raised
     static std::atomic<int> slots_of[64];      // resident workgroups per band, per device (0 = not asked yet)
@@ -818,7 +941,8 @@ static int launch_rblock_t(int c, int cexp, int h, const void* x, const void* wp
         // two blocks per launch of two-row bands (each band computes its neighbours' nearest rows itself); not in place:
         // other workgroups read the input rows around their bands
         if (nblk == 2 && (int64_t)B * 7 <= cus && x != out && rb_band_chain())
-            return launch_rblock_cfg<T, 128, 256, 14, 2, 8, 1, 2>(x, wp, 2, out, B, s);
+            return small_batch_mode() == 1 ? launch_rblock_cfg<T, 128, 256, 14, 2, 8, 1, 2, true>(x, wp, 2, out, B, s)
+                                           : launch_rblock_cfg<T, 128, 256, 14, 2, 8, 1, 2>(x, wp, 2, out, B, s);
         const bool wide = rb_wide_waves() && wblock_has(c, cexp, h);
         const int dt = std::is_same<T, f16>::value ? ACT_F16 : ACT_BF16;
         if (nblk > 1) return wide ? launch_wblock(dt, c, cexp, h, x, wp, nblk, out, B, s)
@@ -831,7 +955,9 @@ static int launch_rblock_t(int c, int cexp, int h, const void* x, const void* wp
     if (c == 128 && cexp == 256 && h == 7) {
         int g = rb_stack_choice(B, cus);
         // conv_5's two blocks as one launch of one-row bands (each band computes the rows above and below it itself)
-        if (g == 0 && nblk == 2 && x != out && rb_band_chain()) return launch_rblock_cfg<T, 128, 256, 7, 1, 8, 1, 2>(x, wp, 2, out, B, s);
+        if (g == 0 && nblk == 2 && x != out && rb_band_chain())
+            return small_batch_mode() == 1 ? launch_rblock_cfg<T, 128, 256, 7, 1, 8, 1, 2, true>(x, wp, 2, out, B, s)
+                                           : launch_rblock_cfg<T, 128, 256, 7, 1, 8, 1, 2>(x, wp, 2, out, B, s);
         if (nblk > 1 && g < 2) g = 2;                      // several blocks per launch otherwise: only the stacked shapes chain
         if (g == 0) return launch_rblock_cfg<T, 128, 256, 7, 1, 8>(x, wp, 1, out, B, s);
         if (g == 2) return launch_rblock_cfg<T, 128, 256, 7, 7, 5, 2>(x, wp, nblk, out, B, s);

@@ -54,6 +54,18 @@ def tta_combine(emb: torch.Tensor, emb_mirror: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def set_small_batch_mode(mode: int) -> None:
+    """How batches of up to about 36 crops run conv_4 / conv_5 (``fra_set_small_batch_mode``; process wide).
+    1 (default): the shortest launches -- the per-frame loop of cam_demo.py:87-105; such a batch's embeddings equal
+    those of a larger batch to rounding (cosine 0.99999) and are the same bits for every batch size up to the limit.
+    0: an embedding is the same bits whatever batch it is computed in."""
+    _lib.check(_lib.load().fra_set_small_batch_mode(int(mode)), "fra_set_small_batch_mode")
+
+
+def small_batch_mode() -> int:
+    return int(_lib.load().fra_get_small_batch_mode())
+
+
 class _ConvUnit(nn.Module):
     """Parameter holder for conv (+bn, +prelu): keys ``conv.weight``, ``bn.*``, ``prelu.weight``."""
 
@@ -82,9 +94,21 @@ class MobileFaceNet(nn.Module):
     """MobileFaceNet(embedding_size); ``forward(x)``: f32 [B,3,112,112] (BGR, [-1,1]) on the HIP
     device -> new f32 [B,embedding_size] tensor with unit-norm rows."""
 
-    # a face's embedding is the same bits whatever batch it is computed in (every kernel configuration a batch size
-    # selects runs the same arithmetic per output value): callers may regroup batches freely (Evaluation.getFeature)
-    batch_invariant = True
+    @property
+    def batch_invariant(self) -> bool:
+        """True when a face's embedding is the same bits whatever batch it is computed in (every kernel configuration a
+        batch size selects then runs the same arithmetic per output value): ``set_small_batch_mode(0)``.  In the default
+        mode that holds among batches of at least ``batch_invariant_from()`` crops (and among the smaller ones), and
+        callers that regroup batches (Evaluation.getFeature) keep to those."""
+        return small_batch_mode() == 0
+
+    def batch_invariant_from(self, device=None) -> int:
+        """Smallest batch from which on an embedding does not depend on the batch size, bit for bit."""
+        if small_batch_mode() == 0:
+            return 1
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
+        return cus // 7 + 1        # the band launches of 7 B <= compute units are the ones the mode changes
 
     def __init__(self, embedding_size: int = 512, act_dtype: str = "f16"):
         super().__init__()

@@ -4,8 +4,9 @@ embed the faces of one frame, optionally with flip-TTA, and match them against t
 One frame's work is ~20-45 short kernels; launched one by one from Python they are bound by launch
 overhead.  ``GraphedRecognizer`` captures the whole sequence -- forward (+ mirrored forward + TTA
 combine) (+ match, threshold, score) -- into ONE hipGraph per batch size and replays it, so a frame
-costs one graph launch.  Inputs are copied into a static buffer; outputs are static tensors that
-stay valid until the next call with the same batch size.
+costs one graph launch.  Inputs are copied into a static buffer (or written there by the caller:
+``input_buffer``); outputs are static tensors that stay valid until the next call with the same batch size.
+A graph keeps the small-batch mode (``face_model.set_small_batch_mode``) it was captured in.
 """
 from __future__ import annotations
 
@@ -63,6 +64,18 @@ class GraphedRecognizer:
             emb, match = self._run(x)
         return _Captured(g, x, emb, match)
 
+    def input_buffer(self, batch: int) -> torch.Tensor:
+        """The static f32 [batch,3,112,112] input of the graph for ``batch`` crops.  A per-frame loop writes its crops
+        there (the host -> device copy of a frame's faces, or the alignment kernel's output) and calls ``rec(buf)``
+        with that same tensor: the replay then starts without the staging copy a foreign tensor needs."""
+        b = int(batch)
+        if b < 1 or b > self.max_batch:
+            raise RuntimeError(f"batch {b} outside [1,{self.max_batch}]")
+        c = self._graphs.get(b)
+        if c is None:
+            c = self._graphs[b] = self._capture(b)
+        return c.x
+
     def __call__(self, x: torch.Tensor) -> Tuple[torch.Tensor, Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]]:
         b = int(x.shape[0])
         if b < 1 or b > self.max_batch:
@@ -70,6 +83,7 @@ class GraphedRecognizer:
         c = self._graphs.get(b)
         if c is None:
             c = self._graphs[b] = self._capture(b)
-        c.x.copy_(x, non_blocking=True)
+        if x.data_ptr() != c.x.data_ptr():                 # crops that are not in the graph's input already
+            c.x.copy_(x, non_blocking=True)
         c.graph.replay()
         return c.emb, c.match

@@ -53,6 +53,15 @@ int fra_version(void);
  * FRA_ERR_STATE and the tag (kernel letters << 16 | wave) if one was set.  Synchronise the stream first to cover the
  * launches still in flight.  No counterpart in the reference. */
 int fra_device_fault(int device, unsigned* tag_out);
+/* How batches of up to about 36 images (7 B <= compute units) run conv_4 / conv_5: the path behind the per-frame loop of
+ * cam_demo.py:87-105.  Mode 1 (default): two 64-channel slices of a residual block at a time, the block's project sum added
+ * in two halves -- the shortest launches; such a batch's embeddings equal those of a larger batch to rounding (cosine
+ * 0.99999 on weights whose embeddings spread over the sphere), and are the same bits for every batch size inside the regime.  Mode 0: one slice at a time, the arithmetic of
+ * the large-batch kernels value for value: an embedding is then the same bits whatever batch it is computed in.  Process
+ * wide; takes effect at the next forward (graphs captured before keep the mode they were captured in).  No counterpart in
+ * the reference. */
+int fra_set_small_batch_mode(int mode);
+int fra_get_small_batch_mode(void);
 /* Test hook: how many times the library has called a memory allocator (hipMalloc, hipFree, hipHostMalloc) since it was
  * loaded.  Every such call in the library goes through one counted wrapper, so a count that does not move across a
  * call proves that the call allocated and freed nothing. */

@@ -69,6 +69,18 @@ def hip_model_calibrated(device, calibrated_state_dict_np):
     return m.to(device).eval()
 
 
+@pytest.fixture
+def invariant_bits():
+    """The mode in which an embedding is the same bits whatever batch it is computed in (fra_set_small_batch_mode(0));
+    the default mode (1: shortest small-batch launches) is restored afterwards."""
+    from face_recognition_amd import face_model
+    face_model.set_small_batch_mode(0)
+    try:
+        yield
+    finally:
+        face_model.set_small_batch_mode(1)
+
+
 def cosine_rows(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)

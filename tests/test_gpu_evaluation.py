@@ -45,7 +45,7 @@ def test_get_feature_and_10fold_vs_oracle(hip_model, device, state_dict_np):
     assert cosine_rows(fl2.numpy(), want).min() >= 0.9999
     # getFeature groups loader batches into forwards of up to 1024 crops (the default for this network); a forward
     # per loader batch, as the reference runs them, gives the same bits
-    assert hip_model.batch_invariant
+    assert hip_model.batch_invariant or hip_model.batch_invariant_from(device) <= 200    # 50 pairs x 4 crops per loader batch
     sl, sr = Evaluation.getFeature(hip_model, _loader(left, right, 50), device, flip=True, group_crops=0)
     assert torch.equal(sl, fl) and torch.equal(sr, fr)
 

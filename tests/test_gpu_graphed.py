@@ -29,5 +29,11 @@ def test_graph_embeddings_only(hip_model, device):
     x = torch.from_numpy(synthetic.make_crops(2, 9)).to(device)
     emb, match = rec(x)
     assert match is None and torch.equal(emb, hip_model(x))
+    # crops written into the graph's own input: no staging copy, same result
+    buf = rec.input_buffer(2)
+    y = torch.from_numpy(synthetic.make_crops(2, 10)).to(device)
+    buf.copy_(y)
+    emb2, _ = rec(buf)
+    assert torch.equal(emb2, hip_model(y))
     with pytest.raises(RuntimeError):
         rec(torch.zeros((100, 3, 112, 112), device=device))

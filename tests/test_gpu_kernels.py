@@ -175,7 +175,17 @@ def test_rblock_chain(device, dt, H, B):
         _lib.check(lib.mfn_op_rblock(code, c, cexp, H, src.data_ptr(), pk.data_ptr() + first * per, 2, two.data_ptr(), B,
                                      stream(device)), "rblock, two blocks")
         torch.cuda.synchronize()
-        assert torch.equal(two, after[first + 1]), first
+        if 7 * B <= torch.cuda.get_device_properties(device).multi_processor_count:
+            # bands of a small batch run two slices of a block side by side and add the two halves of the project sum at
+            # the end (kernels_rblock.hip, dual slices): the one-block launches' values to rounding, the same bits every time
+            close(two, after[first + 1], 2 * rel, f"two blocks per launch, small batch, first block {first}")
+            again = torch.full_like(xd, float("nan"))
+            _lib.check(lib.mfn_op_rblock(code, c, cexp, H, src.data_ptr(), pk.data_ptr() + first * per, 2, again.data_ptr(), B,
+                                         stream(device)), "rblock, two blocks, again")
+            torch.cuda.synchronize()
+            assert torch.equal(two, again), first
+        else:
+            assert torch.equal(two, after[first + 1]), first
     # one launch for all three, written over its own input
     chained = xd.clone()
     _lib.check(lib.mfn_op_rblock(code, c, cexp, H, chained.data_ptr(), pk.data_ptr(), nblk, chained.data_ptr(), B,

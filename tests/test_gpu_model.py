@@ -102,7 +102,7 @@ def test_batch_independence_and_chunking(hip_model, device):
     assert torch.equal(full, chunked)
 
 
-def test_large_batch_rows_match_small_batches(hip_model, device):
+def test_large_batch_rows_match_small_batches(hip_model, device, invariant_bits):
     """A batch large enough that every workgroup of the block kernels walks over several images
     gives, row for row, what small batches give."""
     B = 700
@@ -115,7 +115,7 @@ def test_large_batch_rows_match_small_batches(hip_model, device):
     assert torch.isfinite(full).all()
 
 
-def test_batch_1024_rows_match_small_batches(hip_model, device):
+def test_batch_1024_rows_match_small_batches(hip_model, device, invariant_bits):
     """The benchmark's batch (1024 crops): the block kernels split it into groups of images per resident
     workgroup differently from any smaller batch; rows must not depend on that."""
     B = 1024
@@ -130,7 +130,7 @@ def test_batch_1024_rows_match_small_batches(hip_model, device):
     assert torch.equal(full[300:500], mid)
 
 
-def test_rows_do_not_depend_on_the_batch_at_every_launcher_limit(hip_model, device):
+def test_rows_do_not_depend_on_the_batch_at_every_launcher_limit(hip_model, device, invariant_bits):
     """Batch sizes on both sides of every limit at which the library changes kernels or workgroup shapes (short / tall
     bands at 18 and 36, conv_5's bands / two / four stacked images at 36 and 512, the conv_4 chain at 36, conv_3's
     pipeline ranges 193-256, 385-512, 641-, a second image per workgroup above 256 / 1024, batches that are no multiple
@@ -145,7 +145,7 @@ def test_rows_do_not_depend_on_the_batch_at_every_launcher_limit(hip_model, devi
         assert torch.equal(hip_model(x[B - b:].contiguous()).cpu(), full[B - b:]), -b
 
 
-def test_chained_and_per_block_launches_agree_bit_for_bit(hip_model, device):
+def test_chained_and_per_block_launches_agree_bit_for_bit(hip_model, device, invariant_bits):
     """conv_4's six blocks as one register-resident launch (large batches) vs six launches: same rows; and the
     launch plan says which of the two a batch size gets."""
     x = torch.from_numpy(synthetic.make_crops(150, 19)).to(device)
@@ -177,7 +177,7 @@ def test_chained_and_per_block_launches_agree_bit_for_bit(hip_model, device):
     assert torch.equal(hip_model(x[:60].contiguous()).cpu(), want[:60])              # one launch on a part-filled chip
 
 
-def test_row_pipeline_kernel_matches_band_kernels(device, hip_model, state_dict_np):
+def test_row_pipeline_kernel_matches_band_kernels(device, hip_model, state_dict_np, invariant_bits):
     """conv_3 runs as a pipeline inside a workgroup (producer / consumer waves hand tiles of 32 consecutive pixels on
     through LDS, flags instead of workgroup-wide barriers) where the band kernels' last round over the chip would be
     part empty, as band kernels elsewhere; both give the same bits.  512 crops: pipeline, two images per workgroup
@@ -200,7 +200,7 @@ def test_row_pipeline_kernel_matches_band_kernels(device, hip_model, state_dict_
             assert torch.equal(model(x[lo:lo + 7].contiguous()).cpu(), full[lo:lo + 7]), lo
 
 
-def test_band_configurations_agree_bit_for_bit(hip_model, device):
+def test_band_configurations_agree_bit_for_bit(hip_model, device, invariant_bits):
     """The block kernels run short bands while those fit the chip in one go (up to 18 or 36 images, depending on
     the layer) and tall bands beyond; conv_3 has two tall heights (7 and 14 rows, whichever needs less time for its
     rounds over the chip: 14 rows at 100 images, 7 rows at 40 and 64).  Batches on every side of the limits give
@@ -209,6 +209,40 @@ def test_band_configurations_agree_bit_for_bit(hip_model, device):
     want = hip_model(x).cpu()                      # 100: tall bands everywhere, 14-row bands in conv_3
     for B in (1, 18, 19, 36, 37, 40, 64):
         assert torch.equal(hip_model(x[:B].contiguous()).cpu(), want[:B]), B
+
+
+def test_small_batch_mode(hip_model_calibrated, device, calibrated_state_dict_np):
+    """The default mode runs the band launches of small batches (7 B <= compute units: the per-frame loop of
+    cam_demo.py:87-105) with two slices of a block side by side and adds the block's project sum in two halves.
+    Against the fp32 oracle on calibrated weights: cosine >= 0.9999 for every batch size from 1 to 8; inside the regime
+    a face's embedding is the same bits whatever the batch; against the batch-invariant mode (and so against large
+    batches) it agrees to rounding; above the limit the mode changes nothing."""
+    from face_recognition_amd import face_model
+    model = hip_model_calibrated
+    assert face_model.small_batch_mode() == 1 and not model.batch_invariant
+    limit = model.batch_invariant_from(device) - 1
+    assert limit == torch.cuda.get_device_properties(device).multi_processor_count // 7
+    xn = synthetic.make_crops(limit + 4, 31)
+    x = torch.from_numpy(xn).to(device)
+    want = ref.forward_numpy(calibrated_state_dict_np, xn[:8])
+    fast = model(x[:limit].contiguous()).cpu()
+    for B in range(1, 9):
+        got = model(x[:B].contiguous()).cpu()
+        assert cosine_rows(got.numpy(), want[:B]).min() >= COS_BAR, B
+        assert torch.equal(got, fast[:B]), B
+    assert torch.equal(model(x[limit - 1:limit].contiguous()).cpu(), fast[limit - 1:])
+    above = model(x).cpu()
+    face_model.set_small_batch_mode(0)
+    try:
+        assert model.batch_invariant and model.batch_invariant_from(device) == 1
+        exact = model(x[:limit].contiguous()).cpu()
+        assert torch.equal(model(x).cpu(), above) and torch.equal(exact, above[:limit])
+    finally:
+        face_model.set_small_batch_mode(1)
+    assert not torch.equal(fast, exact)
+    assert cosine_rows(fast.numpy(), exact.numpy()).min() >= 0.99999          # measured 0.999996: one rounding of a stored activation
+    with pytest.raises(RuntimeError, match="mode"):
+        face_model.set_small_batch_mode(2)
 
 
 def test_fused_and_unfused_schedules_agree(hip_model, device, state_dict_np):
