@@ -40,15 +40,15 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 #endif
 constexpr int DW_ROWS = 3, DW_PD = DW_PD_STEPS, DW_RING = DW_PD + 1;   // tap reads run DW_PD steps ahead
 static_assert(DW_PD >= 1 && DW_PD <= 2, "w(q+1)[p] and bias(q+1) must be issued before the taps of the step that uses them");
-constexpr int dw_outstanding(int nt16, int nq, int kind, int st, int n, int nsub = 2) {   // kind 0: taps(st); kind 1: fragment n in step st
+constexpr int dw_outstanding(int nt16, int nq, int kind, int st, int n, int nsub = 2, int pd = DW_PD) {   // kind 0: taps(st); kind 1: fragment n in step st
     const int tap_reads = 2 * nsub;
     int issued = nsub + 1 + DW_ROWS;
     int taps_idx[32] = {};
     int a3_idx[64] = {};
-    for (int i = 0; i < DW_PD; ++i) { issued += tap_reads; taps_idx[i] = issued - 1; }
+    for (int i = 0; i < pd; ++i) { issued += tap_reads; taps_idx[i] = issued - 1; }
     for (int ST = 0; ST < DW_ROWS * nq; ++ST) {
         const int q = ST / DW_ROWS, p = ST % DW_ROWS;
-        if (ST + DW_PD < DW_ROWS * nq) { issued += tap_reads; taps_idx[ST + DW_PD] = issued - 1; }
+        if (ST + pd < DW_ROWS * nq) { issued += tap_reads; taps_idx[ST + pd] = issued - 1; }
         if ((q & 1) && p == 0)
             for (int i = 0; i < cmin(4, nt16); ++i) { issued += 1; a3_idx[i] = issued - 1; }
         if (kind == 0 && st == ST) return cmin(issued - 1 - taps_idx[ST], 15);
@@ -146,9 +146,12 @@ template <typename T, int KS1, int CEXP, int PW1> struct ExpStage {
 // NQ: chunks of the slice this wave handles (4, or 2 = one chunk pair when two waves share a tile)
 // NSUB: 16-pixel subtiles this wave handles (2, or 1 when two waves share a tile: `tb` then points at the wave's subtile)
 // SEP: the second subtile is not a fixed distance from the first: it has tap bases of its own (tbr1, with ROWB == 0)
-template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ, int NSUB = 2, bool SEP = false> struct DwStage {
+// PD: steps the tap reads run ahead of their MFMAs (ring of PD + 1 register sets)
+template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ, int NSUB = 2, bool SEP = false, int PD = DW_PD> struct DwStage {
     typedef typename vec8<T>::type V8;
     typedef typename vec16<T>::type V16;
+    static constexpr int DW_RING = PD + 1;
+    static_assert(PD >= 1 && PD <= 2, "w(q+1)[p] and bias(q+1) must be issued before the taps of the step that uses them");
     V8 er[DW_RING][NSUB][2];       // ring: the two image units of this lane's tap, per subtile
     V8 a3[4];                      // ring: project fragments
     uint32_t w[DW_ROWS];           // this lane's two depthwise weights of each window row (even slot | odd slot << 16)
@@ -207,11 +210,11 @@ template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ, in
         preamble_taps<0>();
     }
     template <int ST> __device__ __forceinline__ void preamble_taps() {
-        if constexpr (ST < DW_PD) { issue_taps<ST>(); preamble_taps<ST + 1>(); }
+        if constexpr (ST < PD) { issue_taps<ST>(); preamble_taps<ST + 1>(); }
     }
     template <int ST, int PAIR, int N = 0> __device__ __forceinline__ void project(f32x4 (&pacc)[NSUB][NT16]) {
         if constexpr (N < NT16) {
-            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a3[N & 3]) : "n"(dw_outstanding(NT16, NQ, 1, ST, N, NSUB)));
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a3[N & 3]) : "n"(dw_outstanding(NT16, NQ, 1, ST, N, NSUB, PD)));
             pacc[0][N] = mfma16(a3[N & 3], bf[0], pacc[0][N]);
             if constexpr (NSUB == 2) pacc[1][N] = mfma16(a3[N & 3], bf[1], pacc[1][N]);
             if constexpr (N + 4 < NT16) {
@@ -225,10 +228,10 @@ template <typename T, int CEXP, int NT16, int PW3, int ST1, int ROWB, int NQ, in
     template <int ST = 0> __device__ __forceinline__ void run(f32x4 (&pacc)[NSUB][NT16]) {
         if constexpr (ST < DW_ROWS * NQ) {
             constexpr int q = ST / DW_ROWS, p = ST % DW_ROWS, slot = ST % DW_RING, par = q & 1;
-            if constexpr (ST + DW_PD < DW_ROWS * NQ) issue_taps<ST + DW_PD>();
+            if constexpr (ST + PD < DW_ROWS * NQ) issue_taps<ST + PD>();
             if constexpr ((q & 1) && p == 0) issue_a3_first<(q >> 1)>();
             // everything issued before taps(ST) has landed with them: w[p], bias (p == 0), slope (p == 2)
-            constexpr int OUT = dw_outstanding(NT16, NQ, 0, ST, 0, NSUB);
+            constexpr int OUT = dw_outstanding(NT16, NQ, 0, ST, 0, NSUB, PD);
             if constexpr (NSUB == 2)
                 asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(er[slot][0][0]), "+v"(er[slot][0][1]), "+v"(er[slot][1][0]), "+v"(er[slot][1][1]), "+v"(w[p]) : "n"(OUT));
             else asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(er[slot][0][0]), "+v"(er[slot][0][1]), "+v"(w[p]) : "n"(OUT));

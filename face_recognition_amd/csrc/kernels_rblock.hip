@@ -167,6 +167,9 @@ extern "C" int fra_dbg_read(void* dst, size_t bytes) {
         else __builtin_amdgcn_s_setprio(2);                                                               \
     } while (0)
 #endif
+#ifndef RB_DS_DW_PD
+#define RB_DS_DW_PD 1      // dual-slice band launches: steps the depthwise stage's tap reads run ahead (2: pair launch 16.1 us against 15.9)
+#endif
 #ifndef RB_SPIN_LIMIT
 #define RB_SPIN_LIMIT (1 << 20)   // polls (some 0.1 s) after which a wait gives up and reports it through `fault` (common.h)
 #endif
@@ -430,7 +433,7 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
     // base: LDS address the package would start at for its depthwise / project group to sit where it does
     auto dwproject = [&](int base, int ioff, int blk = 0) {
         if (CH == 1 ? !dw_active : (wt >= MTO + CH - 1 - blk || en >= 2)) return;   // wave-uniform
-        DwStage<T, 64, NT16, PK::PW3, ST1, PITCH * SLOT, 4, NSUB> dw;
+        DwStage<T, 64, NT16, PK::PW3, ST1, PITCH * SLOT, 4, NSUB, false, (DS ? RB_DS_DW_PD : DW_PD)> dw;
         dw.tb = tb + ioff;
         dw.set_lane(m16, g4);
         dw.w2l = base + PK::OFF_W2 + (g4 & 1) * dw_wplane(64) + m16 * 4;
