@@ -298,6 +298,7 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m16 = lane & 15, g4 = lane >> 4;
     const int y0 = blockIdx.x * TR;                        // first image row of the band
+    RB_T(t_entry);
     const int npk = nblk * NCH;                            // packages of this launch
 
     // ---- package staging: piece k (1 KB) is copied by wave k % NW ----------------------------------------------
@@ -446,6 +447,7 @@ __device__ __forceinline__ void rblock_body(const T* __restrict__ X, const char*
 #ifdef RB_STAMPS
     unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     RB_T(t_begin);
+    RB_ACC(6, t_entry, t_begin);                           // set-up before the loops: zeroed images, lane constants
 #endif
     // ---- epilogue of a block in registers: x <- round((acc + x) + b3), channel for channel what the lane holds; the last
     // block of a launch also stores the image ----

@@ -25,4 +25,4 @@ print("median cycles per wave over %d workgroups, 8 slices (kernel total %.0f)" 
 parts = ("expand", "barrier after expand", "depthwise + project", "block epilogue + package wait", "barrier after the slice", "package request")
 for w in range(8):
     m = np.median(c[:, w, :], axis=0)
-    print("  wave %d: %s" % (w, ", ".join("%s %.0f" % (p, v) for p, v in zip(parts, m[:6]))), " total %.0f" % m[7])
+    print("  wave %d: %s" % (w, ", ".join("%s %.0f" % (p, v) for p, v in zip(parts, m[:6]))), " set-up %.0f  loops %.0f" % (m[6], m[7]))
