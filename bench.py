@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from face_recognition_amd import layers, synthetic  # noqa: E402
+from face_recognition_amd import face_model  # noqa: E402
 from face_recognition_amd.face_model import MobileFaceNet  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, datasheet
@@ -558,7 +559,9 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "input": "f32 NCHW resident in HBM",
                    "output": "f32 [B,512] L2-normalised", "parallelism": f"dp{world}",
                    "batch_chunk": net._batch_chunk, "fused_blocks": net._fused,
-                   "preheat": {"ms": args.preheat_ms, "untimed_steps_before_warmup": preheat_steps}},
+                   "preheat": {"ms": args.preheat_ms, "untimed_steps_before_warmup": preheat_steps},
+                   # 1: batches of up to ~36 crops (the latency lines) add a block's project sum in two halves; 0: batch-invariant bits
+                   "small_batch_mode": face_model.small_batch_mode()},
         "flops_per_face": 2 * layers.macs_per_face(512),
         "forward_tflops": round(faces_per_s * 2 * layers.macs_per_face(512) / 1e12, 2),
     }
