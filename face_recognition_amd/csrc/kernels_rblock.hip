@@ -911,6 +911,14 @@ static int launch_rblock_cfg(const void* x, const void* wp, int nblk, void* out,
 #ifndef RB_NW_WHOLE
 #define RB_NW_WHOLE 8      // waves of a whole-image workgroup (7 tiles of two rows; the eighth wave only stages)
 #endif
+#ifndef RB_DUAL_ROUNDS
+#define RB_DUAL_ROUNDS 1   // rounds of band workgroups over the chip up to which a batch runs the several-blocks-per-band launches in
+                           // dual-slice mode.  Measured with 2 and 3: forward at 37 / 64 / 73 images 245 / 253 / 332 us against
+                           // 220 / 225 / 251 us with whole-image workgroups from 37 on -- a second round doubles a launch's latency
+#endif
+// band workgroups (7 per image) that count as "fit the chip": one round, or RB_DUAL_ROUNDS in dual-slice mode
+static int64_t rb_band_capacity(int cus) { return small_batch_mode() == 1 ? (int64_t)RB_DUAL_ROUNDS * cus : cus; }
+
 // conv_5 (128 -> 256 -> 128 on 7 x 7), workgroup shape by batch size: 0 = one-row bands (7 workgroups per image, one
 // block per launch) while those fit the chip in one go; 2 = two stacked images per workgroup (four tile waves) while
 // a compute unit gets at most RB_STACK2_PER_CU such pairs; 4 = four stacked images (seven tile waves).  2 and 4 chain
@@ -920,7 +928,7 @@ static int launch_rblock_cfg(const void* x, const void* wp, int nblk, void* out,
 static int rb_stack_choice(int B, int cus) {
     static const int forced = [] { const char* e = getenv("FRA_RB_STACK"); return e ? atoi(e) : -1; }();
     if (forced == 0 || forced == 2 || forced == 4) return forced;
-    if ((int64_t)B * 7 <= cus) return 0;
+    if ((int64_t)B * 7 <= rb_band_capacity(cus)) return 0;
     return B <= 2 * RB_STACK2_PER_CU * cus ? 2 : 4;
 }
 
@@ -945,7 +953,7 @@ static int launch_rblock_t(int c, int cexp, int h, const void* x, const void* wp
     if (c == 128 && cexp == 256 && h == 14) {
         // two blocks per launch of two-row bands (each band computes its neighbours' nearest rows itself); not in place:
         // other workgroups read the input rows around their bands
-        if (nblk == 2 && (int64_t)B * 7 <= cus && x != out && rb_band_chain())
+        if (nblk == 2 && (int64_t)B * 7 <= rb_band_capacity(cus) && x != out && rb_band_chain())
             return small_batch_mode() == 1 ? launch_rblock_cfg<T, 128, 256, 14, 2, 8, 1, 2, true>(x, wp, 2, out, B, s)
                                            : launch_rblock_cfg<T, 128, 256, 14, 2, 8, 1, 2>(x, wp, 2, out, B, s);
         const bool wide = rb_wide_waves() && wblock_has(c, cexp, h);
@@ -975,7 +983,7 @@ static int launch_rblock_t(int c, int cexp, int h, const void* x, const void* wp
 int rblock_chain_blocks(int c, int cexp, int h, int B, int remaining) {
     if (remaining < 2) return 1;
     if (rblock_chain_pays(c, cexp, h, B)) return remaining;                 // whole images: the rest of the run in one launch
-    if (c == 128 && cexp == 256 && (h == 14 || h == 7) && (int64_t)B * 7 <= rb_compute_units() && rb_band_chain()) return 2;
+    if (c == 128 && cexp == 256 && (h == 14 || h == 7) && (int64_t)B * 7 <= rb_band_capacity(rb_compute_units()) && rb_band_chain()) return 2;
     return 1;
 }
 
@@ -987,7 +995,7 @@ bool rblock_chain_pays(int c, int cexp, int h, int B) {
     if (c == 128 && cexp == 256 && h == 7) return rb_stack_choice(B, rb_compute_units()) >= 2;
     const bool shape = c == 128 && cexp == 256 && h == 14;
     if (min_b > 0) return shape && B >= min_b;
-    return shape && (int64_t)B * 7 > rb_compute_units();
+    return shape && (int64_t)B * 7 > rb_band_capacity(rb_compute_units());
 }
 
 int launch_rblock(int dt, int c, int cexp, int h, const void* x, const void* wp, int nblk, void* out, int B, hipStream_t s) {
