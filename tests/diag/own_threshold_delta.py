@@ -1,5 +1,5 @@
 """Accuracy of the harness phases with thresholds searched on each side (the reference's protocol), GPU features against
-the fp32 oracle's, for calibrated and for uncalibrated random weights.  python scripts/diag/own_threshold_delta.py [pairs] [noise] [phases]"""
+the fp32 oracle's, for calibrated and for uncalibrated random weights.  python tests/diag/own_threshold_delta.py [pairs] [noise] [phases]"""
 import os
 import sys
 

@@ -94,7 +94,7 @@ def test_reference_protocol_at_lfw_size_and_difficulty(weights, request, device)
     93.4-94.6 %, ten times as many pairs next to the threshold) the same comparison measures -0.12 .. +0.04 pt at 6000 -
     8400 pairs and up to +-0.15 pt at 2000: that figure is recorded, not asserted at 0.1 -- a threshold that is the mean of
     a plateau of equally good grid points moves when one pair's score moves by 0.0006, whatever computed it
-    (scripts/diag/own_threshold_delta.py prints all of these)."""
+    (tests/diag/own_threshold_delta.py prints all of these)."""
     from oracle import evaluation_ref, mobilefacenet_ref
     sd = request.getfixturevalue("calibrated_state_dict_np" if weights == "calibrated" else "state_dict_np")
     model = request.getfixturevalue("hip_model_calibrated" if weights == "calibrated" else "hip_model")
