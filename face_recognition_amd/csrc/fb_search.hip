@@ -222,9 +222,11 @@ __device__ __forceinline__ void fold_chain(Ctx& c, int row0, int rt) {
 // -DSEARCH_PRIO=n (experiments): issue priority inside a step.  1: raised while a wave requests its staging piece;
 // 2: raised for the waves dispatched second (4-7) throughout;  3: raised around the matrix instructions of a step;
 // 4: raised during the list update.  10k queries x 1M / 8M rows, one box, ms: 0: 8.20-8.21 / 58.7-58.8,  1: 8.25 / 58.9,
-// 2: 8.16 / 58.6,  3: 8.36 / 59.7,  4: 8.21 / 58.7 -- nothing outside the run-to-run spread, none adopted
+// 2: 8.16 / 58.6,  3: 8.36 / 59.7,  4: 8.21 / 58.7.  2 against 0 three times each on another box: 8.105-8.149 against
+// 8.169-8.194 ms at 1M rows, 115.35-115.89 against 115.72-116.23 ms at 16M: 0.3-0.5 % every time (the waves dispatched
+// second otherwise get the matrix pipe only when the first ones leave it), adopted
 #ifndef SEARCH_PRIO
-#define SEARCH_PRIO 0
+#define SEARCH_PRIO 2
 #endif
 template <typename T, int KS, int NB, int QTW, int S> struct SearchSteps {
     typedef typename vec8<T>::type V8;
