@@ -126,6 +126,9 @@ void block_kernel(const T* __restrict__ X, const T* __restrict__ W1, const float
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef BK_PRIO_YOUNG       // experiment: the waves dispatched second on each SIMD at raised issue priority (conv_23 0.2167-0.2181 against 0.2135-0.2148 ms: off)
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     const int r = lane & 31, h = lane >> 5;
     const int band = blockIdx.x;
     const int y0 = band * TR;                              // first output row of the band
