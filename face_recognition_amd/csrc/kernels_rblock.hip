@@ -36,6 +36,10 @@
 
 namespace fra {
 
+#ifndef RB_EXP_DEFER
+#define RB_EXP_DEFER 0     // 1: expand stage with a tile's PReLU issued behind the MFMAs of the next tile (Exp16::run); same bits,
+                           // conv_4 chain at batch 1024 301.3-301.6 us against 300.8-302.4: the partner wave already covers that wait
+#endif
 #ifndef RB_EXP_PD
 #define RB_EXP_PD 3        // expand stage: fragment reads run this many steps ahead of their MFMAs
 #endif
@@ -50,7 +54,7 @@ template <typename T, int KS, int PW1, int T0, int NTT> struct Exp16 {
     static_assert(NTT % 2 == 0 && NS > PD, "tiles are written in pairs (one 16-byte unit per pair)");
     V8 fr[NB];
     f32x4 bq[NTT], sl[NTT];
-    f32x4 acc[2];
+    f32x4 acc[2][2];   // [tile parity][subtile]
     V8 o[2];
     int w1l;   // LDS address of this lane's W1 image row 16 (g & 1) + m, unit g >> 1; + 32 t PW1 + 32 ks
     int pl;    // LDS address of the bias quad of channels 4 g ..; + 64 t; slopes 256 further
@@ -64,10 +68,29 @@ template <typename T, int KS, int PW1, int T0, int NTT> struct Exp16 {
         else if constexpr (I < 2 * NTT + PD) { issue_frag<I - 2 * NTT>(); preamble<I + 1>(); }
     }
     static constexpr int outstanding(int S) { return cmin(PD, NS - 1 - S); }
+    // PReLU of values [I0, I1) of tile t (both subtiles) into the output unit of the tile pair: sl = slope - 1
+    template <int t, int I0, int I1> __device__ __forceinline__ void prelu_piece() {
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int i = I0; i < I1; ++i) {
+                const float v = acc[t & 1][st][i];
+                o[st][4 * (t & 1) + i] = (T)fmaf(neg_part(v), sl[t][i], v);
+            }
+    }
+    // positions 16 g + 4 t + i of tiles t = T0 + tl - 1, T0 + tl (tl odd): one 16-byte unit per subtile
+    template <int tl> __device__ __forceinline__ void write_pair(char* lds, const int (&lds_px)[2]) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+            if (lds_px[st] >= 0) *reinterpret_cast<V8*>(lds + lds_px[st] + 8 * (T0 + tl - 1)) = o[st];
+    }
     // lds_px[st]: LDS byte address of this lane's 32-byte share of its pixel slot in subtile st (-1: no pixel)
+    // The PReLU of a tile is issued one tile LATER, a piece behind each MFMA pair of the next tile: its operands have long
+    // left the matrix pipe by then (straight behind the tile's last MFMA it would wait out that instruction's latency).
     template <int S = 0> __device__ __forceinline__ void run(const V8 (&x)[2][KS], char* lds, const int (&lds_px)[2]) {
+        static_assert(4 % KS == 0, "a tile's four values per lane are dealt over its k-steps");
         if constexpr (S < NS) {
-            constexpr int tl = S / KS, ks = S % KS, slot = S % NB;
+            constexpr int tl = S / KS, ks = S % KS, slot = S % NB, a = tl & 1;
             if constexpr (S + PD < NS) issue_frag<S + PD>();
             if constexpr (ks == 0)
                 asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fr[slot]), "+v"(bq[tl]) : "n"(outstanding(S)));
@@ -76,29 +99,31 @@ template <typename T, int KS, int PW1, int T0, int NTT> struct Exp16 {
             else
                 asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fr[slot]) : "n"(outstanding(S)));
             if constexpr (ks == 0) {
-                acc[0] = mfma16(fr[slot], x[0][0], bq[tl]);
-                acc[1] = mfma16(fr[slot], x[1][0], bq[tl]);
+                acc[a][0] = mfma16(fr[slot], x[0][0], bq[tl]);
+                acc[a][1] = mfma16(fr[slot], x[1][0], bq[tl]);
             } else {
-                acc[0] = mfma16(fr[slot], x[0][ks], acc[0]);
-                acc[1] = mfma16(fr[slot], x[1][ks], acc[1]);
+                acc[a][0] = mfma16(fr[slot], x[0][ks], acc[a][0]);
+                acc[a][1] = mfma16(fr[slot], x[1][ks], acc[a][1]);
             }
             __builtin_amdgcn_sched_barrier(0);             // keep each MFMA pair right behind its wait
-            if constexpr (ks == KS - 1) {
-#pragma unroll
-                for (int st = 0; st < 2; ++st)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float v = acc[st][i];
-                        o[st][4 * (tl & 1) + i] = (T)fmaf(neg_part(v), sl[tl][i], v);   // PReLU: sl = slope - 1
-                    }
-                if constexpr (tl & 1) {
-                    // positions 16 g + 4 t + i of tiles t = T0 + tl - 1, T0 + tl: one 16-byte unit
-#pragma unroll
-                    for (int st = 0; st < 2; ++st)
-                        if (lds_px[st] >= 0) *reinterpret_cast<V8*>(lds + lds_px[st] + 8 * (T0 + tl - 1)) = o[st];
-                }
+#if RB_EXP_DEFER
+            if constexpr (tl > 0) {
+                prelu_piece<tl - 1, ks * (4 / KS), (ks + 1) * (4 / KS)>();
+                if constexpr (ks == KS - 1 && ((tl - 1) & 1)) write_pair<tl - 1>(lds, lds_px);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (S == NS - 1) {                   // the last tile has no successor to hide behind
+                prelu_piece<tl, 0, 4>();
+                if constexpr (tl & 1) write_pair<tl>(lds, lds_px);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
+            if constexpr (ks == KS - 1) {
+                prelu_piece<tl, 0, 4>();
+                if constexpr (tl & 1) write_pair<tl>(lds, lds_px);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
             run<S + 1>(x, lds, lds_px);
         }
     }
