@@ -71,6 +71,7 @@ SIGNATURES = {
     "fb_search_l2_topk_noalloc": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "fb_merge_topk": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "fb_threshold_score": (_I, [_P, _P, _P, _I, _D, _P]),
+    "fb_match_nearest": (_I, [_P, _P, _I, _D, _P, _P, _P, _P]),
     "fb_destroy": (_I, [_P]),
     "ev_fold_scores": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "fa_align_warp": (_I, [_P, _I, _I, _P, _I, _P, _I, _I, _P]),

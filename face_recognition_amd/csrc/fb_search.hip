@@ -663,6 +663,49 @@ __global__ __launch_bounds__(256) void threshold_score_kernel(const float* __res
     score[i] = fminf(fmaxf(sc, 0.0f), 100.0f);
 }
 
+// The demos' whole post-processing of one query's distance row in one launch (cam_demo.py:98-105): the nearest row --
+// the lexicographically smallest (distance, index) pair, as select_topk_kernel's first round picks it --, its index as
+// int64 or -1 beyond the threshold, and the score of threshold_score_kernel.  One block per query.
+__global__ __launch_bounds__(256) void match_nearest_kernel(const float* __restrict__ dist, long N, int index_base,
+                                                            float limit, float* __restrict__ minimum,
+                                                            long long* __restrict__ idx_out, float* __restrict__ score) {
+    __shared__ float sd[4];
+    __shared__ int si[4];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = dist + (size_t)q * N;
+    float bd = INFINITY;
+    int bi = 0x7fffffff;
+    for (long c = tid; c < N; c += 256) {
+        const float d = row[c];
+        const int i = (int)c + index_base;
+        if (pair_less(d, i, bd, bi)) { bd = d; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float od = __shfl_xor(bd, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (pair_less(od, oi, bd, bi)) { bd = od; bi = oi; }
+    }
+    if (lane == 0) { sd[wave] = bd; si[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        bd = sd[0]; bi = si[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (pair_less(sd[w], si[w], bd, bi)) { bd = sd[w]; bi = si[w]; }
+        const bool found = bi != 0x7fffffff;
+        const float m = found ? bd : INFINITY;
+        minimum[q] = m;
+        idx_out[q] = (!found || m > limit) ? -1 : (long long)bi;          // cam_demo.py:100
+        float sc;
+        {
+#pragma clang fp contract(off)
+            sc = m * -80.0f + 156.0f;                                      // cam_demo.py:105: two roundings, as there
+        }
+        score[q] = fminf(fmaxf(sc, 0.0f), 100.0f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 static void launch_select(hipStream_t s, int Q, const float* dist, const int* idx, int lists, long strideL, long strideQ, int len,
                           int index_base, int k, float* dist_out, int* idx_out) {
@@ -1121,6 +1164,35 @@ int fb_threshold_score(const float* minimum, int64_t* idx_io, float* score_100, 
     hipLaunchKernelGGL(threshold_score_kernel, dim3((Q + 255) / 256), dim3(256), 0, (hipStream_t)stream, minimum,
                        reinterpret_cast<long long*>(idx_io), score_100, Q, limit);
     FRA_HIP(hipGetLastError());
+    return FRA_OK;
+}
+
+int fb_match_nearest(fb_handle* h, const float* queries, int Q, double threshold, float* minimum, int64_t* idx_out,
+                     float* score_100, fra_stream stream) {
+    FRA_REQUIRE(h && queries && minimum && idx_out && score_100, FRA_ERR_ARG, "fb_match_nearest: null pointer");
+    FRA_REQUIRE(Q > 0, FRA_ERR_ARG, "fb_match_nearest: Q=%d", Q);
+    FRA_REQUIRE(h->store == FRA_F32, FRA_ERR_ARG, "fb_match_nearest: the gallery must hold fp32 rows (the demos' exact match)");
+    FRA_REQUIRE(h->N >= 1 && h->N < 2147483647L, FRA_ERR_ARG, "fb_match_nearest: gallery of %lld rows", (long long)h->N);
+    FRA_DEVICE(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t row_bytes = (size_t)h->N * 4;
+    FRA_REQUIRE(row_bytes <= F32_SCRATCH_CAP, FRA_ERR_ARG, "fb_match_nearest: gallery too large for the fp32 path");
+    int qc = (int)(F32_SCRATCH_CAP / row_bytes);
+    if (qc > Q) qc = Q;
+    char* sc = nullptr;
+    if (int rc = take_scratch(h, align_up((size_t)qc * row_bytes, 256), nullptr, 0, &sc)) return rc;
+    float* dist = reinterpret_cast<float*>(sc);
+    const float limit = (float)((threshold - 156.0) / (-80.0));  // python float, then compared in fp32
+    for (int q0 = 0; q0 < Q; q0 += qc) {
+        const int m = (Q - q0) < qc ? (Q - q0) : qc;
+        const long pairs = (long)m * h->N;
+        FRA_REQUIRE((pairs + 3) / 4 < 2147483647L, FRA_ERR_ARG, "fb_match_nearest: Q*N too large");
+        hipLaunchKernelGGL(l2dist_f32_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, queries + (size_t)q0 * h->D,
+                           static_cast<const float*>(h->rows), dist, m, (long)h->N, h->D);
+        hipLaunchKernelGGL(match_nearest_kernel, dim3(m), dim3(256), 0, s, dist, (long)h->N, (int)h->index_base, limit,
+                           minimum + q0, reinterpret_cast<long long*>(idx_out) + q0, score_100 + q0);
+        FRA_HIP(hipGetLastError());
+    }
     return FRA_OK;
 }
 

@@ -208,6 +208,18 @@ def match_facebank(source_embs: torch.Tensor, targets: Union[torch.Tensor, Galle
     then the reference's '' = unknown slot), and ``clamp(-80*minimum+156, 0, 100)``.
     """
     g = _as_gallery(targets, "f32")
+    if g.store == "f32" and g.n > 0:          # the demos' case: distances, nearest row, threshold and score in two launches
+        if source_embs.dim() != 2 or source_embs.shape[1] != g.d or source_embs.shape[0] == 0:
+            raise RuntimeError(f"queries must be [Q,{g.d}] with Q > 0, got {tuple(source_embs.shape)}")
+        q = source_embs.detach().to(g.device, torch.float32).contiguous()
+        minimum = torch.empty(q.shape[0], dtype=torch.float32, device=g.device)
+        min_idx = torch.empty(q.shape[0], dtype=torch.int64, device=g.device)
+        score = torch.empty_like(minimum)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.load().fb_match_nearest(g._h, q.data_ptr(), q.shape[0], float(threshold), minimum.data_ptr(),
+                                                    min_idx.data_ptr(), score.data_ptr(), _lib.current_stream_ptr(g.device)),
+                       "fb_match_nearest")
+        return minimum, min_idx, score
     dist, idx = g.search(source_embs, 1)
     minimum = dist[:, 0].contiguous()
     min_idx = idx[:, 0].to(torch.int64).contiguous()

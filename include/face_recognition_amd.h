@@ -249,6 +249,13 @@ int fb_search_l2_topk_noalloc(fb_handle* h, const float* queries, int Q, int k, 
 int fb_merge_topk(const float* dist_in, const int32_t* idx_in, int R, int Q, int k, float* dist_out,
                   int32_t* idx_out, fra_stream stream);
 
+/* The demos' match step in one call (cam_demo.py:96-105): for each query the squared L2 distance to the nearest row of
+ * an fp32 gallery (minimum dev f32 [Q]), that row's index as int64 -- -1 where minimum > (threshold-156)/(-80) -- and
+ * clamp(-80*minimum+156, 0, 100) (score_100 dev f32 [Q]); the values of fb_search_l2_topk(k = 1) followed by
+ * fb_threshold_score, in two kernel launches instead of four. */
+int fb_match_nearest(fb_handle* h, const float* queries, int Q, double threshold, float* minimum, int64_t* idx_out,
+                     float* score_100, fra_stream stream);
+
 /* Demo post-processing on top-1 results (cam_demo.py:100,105): idx_io[q] = -1 where
  * minimum[q] > (threshold-156)/(-80); score_100[q] = clamp(-80*minimum[q]+156, 0, 100). */
 int fb_threshold_score(const float* minimum, int64_t* idx_io, float* score_100, int Q, double threshold,
